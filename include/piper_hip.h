@@ -1,0 +1,319 @@
+/*
+ * piper_hip.h — C-ABI of the MI355X (gfx950) operator backend for Piper VITS inference.
+ *
+ * This is the drop-in boundary for the slot `Sources/PiperMetal` fills in ocrickard/piper-swift:
+ * one entry point per `MetalBackend` per-op method that `GraphExecutor.executeNode` calls on the
+ * hot path, plus fused / whole-utterance entry points whose results equal the
+ * unfused composition.  Every declaration cites the reference interface it replaces (file:line,
+ * relative to the reference repo root).
+ *
+ * Conventions (mirroring MetalBackend):
+ *   - Tensors are dense row-major float32 on the device; shapes are int64_t arrays.
+ *   - The callee ALLOCATES and returns the output buffer (MetalBackend returns a fresh MTLBuffer,
+ *     MetalBackend.swift:1184, 1261, 1334).  If `*out` is non-NULL on entry it is used instead
+ *     (caller-owned, must hold the output) — the zero-allocation path for static schedules.
+ *   - Inputs are borrowed and never written.
+ *   - `stream == NULL`  ⇔ `commandBuffer == nil`: run and BLOCK until complete
+ *     (MetalBackend.swift:1223-1226).  Non-NULL ⇔ encode only; `piper_hip_stream_sync` ⇔ `flush`.
+ *   - Swift `throws` → int status (0 ok, negative below) + thread-local `piper_hip_last_error()`.
+ *   - One context per GPU, used from one host thread at a time (the reference has one queue, one
+ *     executor, no locks: GraphExecutor.swift:27, MetalContext.swift:6,14).
+ *   - No CPU fallback exists anywhere behind this header: without a gfx950 device every compute
+ *     entry point returns PIPER_HIP_ERR_UNAVAILABLE.
+ */
+#ifndef PIPER_HIP_H
+#define PIPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIPER_HIP_ABI_VERSION 1
+
+/* ---- status codes: ExecutionError (CPUBackend.swift:3-17) + NSError domain "MetalBackend" ---- */
+enum {
+  PIPER_HIP_OK = 0,
+  PIPER_HIP_ERR_SHAPE = -1,       /* ExecutionError.shapeMismatch */
+  PIPER_HIP_ERR_TYPE = -2,        /* ExecutionError.typeMismatch */
+  PIPER_HIP_ERR_UNSUPPORTED = -3, /* ExecutionError.unsupportedOp */
+  PIPER_HIP_ERR_UNAVAILABLE = -4, /* ExecutionError.metalUnavailable: no gfx950 device / HIP init failed */
+  PIPER_HIP_ERR_ALLOC = -5,       /* NSError 600/610/620/760/904: output allocation failed */
+  PIPER_HIP_ERR_LAUNCH = -6,      /* NSError 601/611/621/761/900: encode / execution failed */
+  PIPER_HIP_ERR_ARG = -7          /* NULL / invalid handle (Swift's type system excludes these) */
+};
+
+typedef struct piper_hip_ctx piper_hip_ctx;     /* MetalBackend + MetalContext (device, queue, pipelines) */
+typedef struct piper_hip_voice piper_hip_voice; /* a loaded voice: weights resident + static schedule */
+typedef void* piper_hip_stream;                 /* hipStream_t; stands in for MTLCommandBuffer? */
+
+/* Thread-local description of the last failure on this thread ("" if none). */
+const char* piper_hip_last_error(void);
+int piper_hip_abi_version(void);
+/* Number of visible HIP devices (0 when none); never initialises a device. */
+int piper_hip_device_count(void);
+
+/* ---- context, buffers, transfers ---- */
+/* MetalContext.init (Metal/MetalContext.swift:9-33) + MetalBackend.init (MetalBackend.swift:12-15). */
+int piper_hip_create(int device, piper_hip_ctx** out);
+void piper_hip_destroy(piper_hip_ctx* ctx);
+/* MetalBackend.allocateBuffer(length:) (MetalBackend.swift:34-39): at least 1 byte is allocated. */
+int piper_hip_alloc(piper_hip_ctx* ctx, size_t bytes, void** out);
+/* Buffer release (ARC drop in the reference; GraphExecutor.swift:216-225). Returns memory to the
+ * context pool; stream-ordered with respect to work already enqueued on the context's streams. */
+int piper_hip_free(piper_hip_ctx* ctx, void* buf);
+/* MetalBackend.uploadFloat32 (MetalBackend.swift:983-993). */
+int piper_hip_upload_f32(piper_hip_ctx* ctx, const float* host, size_t count, float** out);
+int piper_hip_upload_i64(piper_hip_ctx* ctx, const int64_t* host, size_t count, int64_t** out);
+/* MetalBackend.downloadFloat32 (MetalBackend.swift:963-981): blocks until `buf` is complete. */
+int piper_hip_download_f32(piper_hip_ctx* ctx, const float* buf, float* host, size_t count);
+/* MetalBackend.makeCommandBuffer / flush / flushWithTimings (MetalBackend.swift:841-874). */
+int piper_hip_stream_create(piper_hip_ctx* ctx, piper_hip_stream* out);
+int piper_hip_stream_destroy(piper_hip_ctx* ctx, piper_hip_stream s);
+int piper_hip_stream_sync(piper_hip_ctx* ctx, piper_hip_stream s);
+/* GPU time bracket on a stream (gpuStartTime/gpuEndTime, MetalBackend.swift:868-873). */
+int piper_hip_timer_begin(piper_hip_ctx* ctx, piper_hip_stream s);
+int piper_hip_timer_end(piper_hip_ctx* ctx, piper_hip_stream s, double* gpu_ms); /* syncs the stream */
+
+/* ---- param PODs (MetalBackend.swift:876-961; MSL twins conv1d.metal:12-26,80-95) ---- */
+typedef struct {
+  int32_t stride, dilation, pad_l, pad_r, groups;
+} piper_hip_conv1d_params;
+typedef struct {
+  int32_t stride, dilation, pad_l, pad_r, output_padding, groups;
+} piper_hip_convtranspose1d_params;
+
+typedef enum { /* unaryF32 / unaryAlphaF32 kernels (MetalBackend.swift:1501-1586; elementwise.metal:165-312) */
+  PIPER_HIP_RELU = 0,
+  PIPER_HIP_LEAKYRELU = 1, /* alpha */
+  PIPER_HIP_TANH = 2,
+  PIPER_HIP_SIGMOID = 3,
+  PIPER_HIP_EXP = 4,
+  PIPER_HIP_NEG = 5,
+  PIPER_HIP_SQRT = 6,
+  PIPER_HIP_SOFTPLUS = 7,
+  PIPER_HIP_CEIL = 8,
+  PIPER_HIP_ERF = 9
+} piper_hip_unary_op;
+typedef enum { /* add/sub/mul/div/pow broadcast kernels (MetalBackend.swift:2592-2610; elementwise.metal:52-130) */
+  PIPER_HIP_ADD = 0,
+  PIPER_HIP_SUB = 1,
+  PIPER_HIP_MUL = 2,
+  PIPER_HIP_DIV = 3,
+  PIPER_HIP_POW = 4
+} piper_hip_binary_op;
+
+/* ---- per-op entry points (§8a rows a3-a9) ---- */
+
+/* MetalBackend.conv1dF32 (MetalBackend.swift:1149-1228) → conv1d_f32 (conv1d.metal:28-71);
+ * arithmetic spec CPUBackend.conv1d (CPUBackend.swift:20-73).
+ * x [N,Cin,L], w [Cout,Cin/g,K], bias [Cout] or NULL → y [N,Cout,L_out],
+ * L_out = (L + pad_l + pad_r − dilation·(K−1) − 1)/stride + 1 (integer division). */
+int piper_hip_conv1d_f32(piper_hip_ctx* ctx, const float* x, const int64_t x_shape[3], const float* w,
+                         const int64_t w_shape[3], const float* bias, const piper_hip_conv1d_params* p,
+                         float** out, int64_t out_shape[3], piper_hip_stream stream);
+
+/* MetalBackend.convTranspose1dF32 (MetalBackend.swift:2812-2895) → convtranspose1d_f32
+ * (conv1d.metal:97-142). w is ONNX layout [Cin, Cout/g, K].
+ * L_out = (L−1)·stride − pad_l − pad_r + dilation·(K−1) + output_padding + 1 (must be > 0). */
+int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, const int64_t x_shape[3], const float* w,
+                                  const int64_t w_shape[3], const float* bias,
+                                  const piper_hip_convtranspose1d_params* p, float** out, int64_t out_shape[3],
+                                  piper_hip_stream stream);
+
+/* MetalBackend.matmulF32 (MetalBackend.swift:1232-1323) → matmul_f32 (matmul.metal:22-49), with the
+ * executor's rank-4 lead-dim broadcast (GraphExecutor.swift:1870-1899) done by stride-0 addressing
+ * instead of a materialised expandF32.  Equal ranks ≥ 2 required (MetalBackend.swift:1236-1238);
+ * lead dims must be equal or 1-broadcastable. */
+int piper_hip_matmul_f32(piper_hip_ctx* ctx, const float* a, const int64_t* a_shape, const float* b,
+                         const int64_t* b_shape, int rank, float** out, int64_t* out_shape,
+                         piper_hip_stream stream);
+
+/* MetalBackend.softmaxLastDimF32 (MetalBackend.swift:1326-1355) → softmax_lastdim_f32
+ * (softmax.metal:13-41). Last dim must be > 0. */
+int piper_hip_softmax_lastdim_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank, float** out,
+                                  piper_hip_stream stream);
+
+/* MetalBackend.{relu,leakyRelu,tanh,sigmoid,exp,neg,sqrt,softplus,ceil,erf}F32
+ * (MetalBackend.swift:1501-1586). `alpha` is read only by PIPER_HIP_LEAKYRELU. */
+int piper_hip_unary_f32(piper_hip_ctx* ctx, piper_hip_unary_op op, const float* x, size_t count, float alpha,
+                        float** out, piper_hip_stream stream);
+
+/* MetalBackend.{add,sub,mul,div,pow}F32 → binaryBroadcastF32 (MetalBackend.swift:2099-2134, 2592-2610);
+ * NumPy broadcasting, output rank ≤ 4 (MetalBackend.swift:2065-2067). out_shape has max(ra,rb) entries. */
+int piper_hip_binary_broadcast_f32(piper_hip_ctx* ctx, piper_hip_binary_op op, const float* a,
+                                   const int64_t* a_shape, int a_rank, const float* b, const int64_t* b_shape,
+                                   int b_rank, float** out, int64_t* out_shape, int* out_rank,
+                                   piper_hip_stream stream);
+
+/* Layout ops the rel-position skew and the flow coupling are made of (§8a rows a7, a9). */
+/* MetalBackend.padConstantF32 (MetalBackend.swift:780-839) → pad_constant_f32_rank4 (pad.metal).
+ * pads = [begin_0..begin_{r-1}, end_0..end_{r-1}], all ≥ 0, rank ≤ 4. */
+int piper_hip_pad_constant_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank,
+                               const int64_t* pads, float value, float** out, int64_t* out_shape,
+                               piper_hip_stream stream);
+/* Slice arms (GraphExecutor.swift:1322-1426) → slice.metal kernels. One axis, start/end already
+ * clamped ONNX-style by the caller, step ≠ 0 (step −1 on axis 1 is VITS `Flip`). rank ≤ 4. */
+int piper_hip_slice_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank, int axis, int64_t start,
+                        int64_t end, int64_t step, float** out, int64_t* out_shape, piper_hip_stream stream);
+/* MetalBackend.transposeF32 (MetalBackend.swift:995-1060) → transpose_f32_rank4 (transpose.metal:16-46). */
+int piper_hip_transpose_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank, const int32_t* perm,
+                            float** out, int64_t* out_shape, piper_hip_stream stream);
+/* concat2_axis1_ncl_f32 / split2_axis1_ncl_f32 (tensorops.metal; GraphExecutor.swift:1107-1124, 2254-2262). */
+int piper_hip_concat2_axis1_f32(piper_hip_ctx* ctx, const float* a, const int64_t a_shape[3], const float* b,
+                                const int64_t b_shape[3], float** out, int64_t out_shape[3],
+                                piper_hip_stream stream);
+int piper_hip_split2_axis1_f32(piper_hip_ctx* ctx, const float* x, const int64_t x_shape[3], int64_t c0,
+                               float** out0, float** out1, piper_hip_stream stream);
+/* MetalBackend.expandF32 (MetalBackend.swift:2438-2458) → expand_f32_rank4 (expand.metal). */
+int piper_hip_expand_f32(piper_hip_ctx* ctx, const float* x, const int64_t* in_shape, const int64_t* out_shape,
+                         int rank, float** out, piper_hip_stream stream);
+/* reduce_mean_lastdim_f32 (reduce.metal:12-25; MetalBackend.swift:1357-1390) — the LayerNorm building block. */
+int piper_hip_reduce_mean_lastdim_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank,
+                                      float** out, piper_hip_stream stream);
+
+/* ---- fused entry points: results equal the unfused composition of the ops above ---- */
+
+/* Text-encoder relative-position self-attention core (§8a rows a5+a6+a7), one call per layer:
+ *   scores = (q/√d)·kᵀ + rel→abs( (q/√d)·E_kᵀ );  p = softmax(scores);  out = p·v + abs→rel(p)·E_v
+ * q,k,v: [N, H·d, T] channel-major (the k=1 Conv outputs, head h = channels [h·d,(h+1)·d));
+ * emb_rel_k/emb_rel_v: [2·window+1, d] shared over heads; out: [N, H·d, T].
+ * Replaces the MatMul/Pad/Reshape/Slice/Softmax/Transpose chain of GraphExecutor.swift:1862-1929,
+ * 1130-1210, 1371-1426, 901-947 without materialising [N,H,T,2T−1]. */
+int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, const float* k, const float* v,
+                                const float* emb_rel_k, const float* emb_rel_v, int64_t n, int64_t heads,
+                                int64_t head_dim, int64_t t, int64_t window, float** out, piper_hip_stream stream);
+
+/* Channel LayerNorm with fused residual: out = LN_c(x + y)·gamma + beta over C for each (n,t); y may be
+ * NULL. Replaces Transpose + ReduceMean/Sub/Pow/Sqrt/Div/Mul/Add (GraphExecutor.swift:2071-2125). */
+int piper_hip_add_layernorm_f32(piper_hip_ctx* ctx, const float* x, const float* y, const float* gamma,
+                                const float* beta, int64_t n, int64_t c, int64_t t, float eps, float** out,
+                                piper_hip_stream stream);
+
+/* One WaveNet layer of the flow (§8a rows a3+a8): acts = tanh(a)·sigmoid(b), [a;b] = in_conv(x) (C→2C, k, dilation);
+ * rs = res_skip_conv(acts) (k=1; C→2C, or C→C when `last`). If !last: x_out = x + rs[:C], skip_out = skip_in + rs[C:];
+ * else skip_out = skip_in + rs. skip_in may be NULL (treated as 0). x_out/skip_out follow the `*out` convention
+ * (x_out is not written when `last`). */
+int piper_hip_wavenet_layer_f32(piper_hip_ctx* ctx, const float* x, const float* skip_in, const float* w_in,
+                                const float* b_in, const float* w_rs, const float* b_rs, int64_t n, int64_t c,
+                                int64_t t, int64_t k, int64_t dilation, int last, float** x_out, float** skip_out,
+                                piper_hip_stream stream);
+
+/* HiFi-GAN residual blocks (§8a rows a3+a8). type 1 (Piper "high"): for each dilation d_i:
+ * x = x + conv2_i(lrelu(conv1_i(lrelu(x)), d=d_i), d=1); type 2 (Piper "medium"): x = x + conv_i(lrelu(x), d=d_i).
+ * slope 0.1 (LeakyRelu alpha), `same` padding (k·d−d)/2. weights: n_dil (type 2) or 2·n_dil (type 1, ordered
+ * c1_0,c2_0,c1_1,…) tensors [C,C,K] each followed by its bias [C], as arrays of device pointers on the host. */
+int piper_hip_hifigan_resblock_f32(piper_hip_ctx* ctx, int type, const float* x, int64_t n, int64_t c, int64_t t,
+                                   int64_t k, const int32_t* dilations, int n_dil, const float* const* weights,
+                                   const float* const* biases, float lrelu_slope, float** out,
+                                   piper_hip_stream stream);
+
+/* ---- whole-utterance path: PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80) ---- */
+
+#define PIPER_HIP_MAX_UPS 4
+#define PIPER_HIP_MAX_RB 3
+typedef struct {
+  int32_t n_vocab;    /* embedding rows (Piper num_symbols, 256) */
+  int32_t hidden;     /* 192 */
+  int32_t n_heads;    /* 2 */
+  int32_t n_layers;   /* 6 */
+  int32_t ffn;        /* 768 */
+  int32_t ffn_kernel; /* 3 */
+  int32_t window;     /* 4 */
+  int32_t inter;      /* 192 */
+  int32_t n_flows;    /* 4 */
+  int32_t wn_layers;  /* 4 */
+  int32_t wn_kernel;  /* 5 */
+  int32_t up_initial; /* 256 (medium) / 512 (high) */
+  int32_t n_ups;      /* 3 / 4 */
+  int32_t up_rates[PIPER_HIP_MAX_UPS];
+  int32_t up_kernels[PIPER_HIP_MAX_UPS];
+  int32_t resblock_type; /* 2 (medium) / 1 (high) */
+  int32_t n_rb;          /* resblocks per stage (3) */
+  int32_t rb_kernels[PIPER_HIP_MAX_RB];
+  int32_t rb_n_dil; /* dilations per resblock: 2 (medium) / 3 (high) */
+  int32_t rb_dilations[PIPER_HIP_MAX_RB][3];
+  int32_t sample_rate; /* 22050 */
+} piper_hip_voice_config;
+
+/* Piper medium / high geometry (SURVEY.md §8a †). quality: 0 = medium, 1 = high. */
+int piper_hip_voice_config_preset(int quality, piper_hip_voice_config* out);
+/* Number of floats in the packed weight blob for `cfg` (layout: include/piper_hip_voice_layout.h). */
+int piper_hip_voice_blob_floats(const piper_hip_voice_config* cfg, size_t* n_floats);
+/* One tensor of the blob (order = include/piper_hip_voice_layout.h). kind: 0 weight, 1 bias, 2 gamma, 3 beta, 4 embedding. */
+typedef struct {
+  char name[96];
+  int32_t kind;
+  int32_t rank;
+  int64_t shape[3];
+  int64_t fan_in;
+  uint64_t offset; /* floats */
+  uint64_t count;  /* floats */
+} piper_hip_tensor_info;
+int piper_hip_voice_blob_layout(const piper_hip_voice_config* cfg, piper_hip_tensor_info* out, int max_entries,
+                                int* n_entries);
+/* Fill a HOST blob with synthetic weights: the bench has no real voice offline. Counter-based
+ * SplitMix64 → 24-bit uniform, zero-mean with the variance SURVEY.md §8d asks for (weights/embeddings
+ * U(±√(3/fan_in)) ⇒ var 1/fan_in; biases U(±0.01·√3); gamma 1+U(±0.1); beta U(±0.1)) — uniform instead of
+ * Box-Muller so that C and numpy (tests/katdata.py) produce bit-identical blobs. Host-only, no GPU needed. */
+int piper_hip_voice_synthetic_blob(const piper_hip_voice_config* cfg, uint64_t seed, float* host_blob,
+                                   size_t n_floats);
+/* Load a voice from a packed fp32 blob; `on_device` ≠ 0 when `blob` is a device pointer (e.g. the RCCL-broadcast
+ * copy). Packs MFMA weight fragments once; the blob itself is not retained. ⇔ GraphExecutor.init + persistent
+ * initializer buffers (GraphExecutor.swift:42-71, 279-283). */
+int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_config* cfg, const float* blob, int on_device,
+                           piper_hip_voice** out);
+void piper_hip_voice_destroy(piper_hip_voice* v);
+
+/* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104). The duration
+ * predictor is outside this library's scope, so per-id frame counts are supplied (the reference's own
+ * `overrides` mechanism); `noise` is the "main" RandomNormalLike tensor [inter, F] injected by name
+ * (PiperTestVector.swift:24-29), HOST pointer, or NULL for zeros. */
+typedef struct {
+  const int64_t* phoneme_ids; /* [T] host */
+  int32_t t;
+  const int32_t* durations; /* [T] host, frames per id (≥0); F = Σ durations */
+  const float* noise;       /* [inter, F] host, may be NULL */
+  float noise_scale;        /* scales[0] */
+} piper_hip_utterance;
+
+/* Samples `synthesize` will produce for this utterance (F · Π up_rates). */
+int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_utterance* u);
+/* Prepare (and cache) the static schedule + HIP graph + arena for this utterance's (T,F) and upload its
+ * inputs; returns a slot id ≥ 0. A slot is an independent stream + arena, so several prepared utterances
+ * can be launched back-to-back and overlap on the GPU. */
+int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot);
+/* Enqueue the prepared slot's forward pass (one hipGraphLaunch). No host sync. */
+int piper_hip_voice_launch(piper_hip_voice* v, int slot);
+/* Wait for the slot and copy the waveform [num_samples] to host (NULL = just wait). */
+int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples);
+/* prepare + launch + collect: PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80). */
+int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u, float* host_audio,
+                               int64_t max_samples, int64_t* n_samples);
+/* Debug taps ⇔ GraphExecutor.execute(maxNodeIndex:) returning intermediates (GraphExecutor.swift:75-152):
+ * copy a named intermediate of the slot's last run to host. Names: "enc_out" [H,T], "m_p" [inter,T],
+ * "logs_p" [inter,T], "z_p" [inter,F], "z" [inter,F], "dec_pre" [up_initial,F]. */
+int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name, float* host, size_t max_floats,
+                        size_t* n_floats);
+/* GPU milliseconds of the slot's last completed launch (hipEvent pair on the slot's stream) ⇔
+ * RunTimings.gpuMs (GraphExecutor.swift:29-38). */
+int piper_hip_voice_last_gpu_ms(piper_hip_voice* v, int slot, double* ms);
+/* Stream of a slot (for external event timing / profiling). */
+piper_hip_stream piper_hip_voice_slot_stream(piper_hip_voice* v, int slot);
+/* Per-kernel timing of the slot's schedule: runs the schedule eagerly `iters` times with a hipEvent pair
+ * around every launch; fills up to `max_entries` entries sorted by schedule order. */
+typedef struct {
+  char name[48];
+  double avg_us;     /* mean launch duration */
+  double flops;      /* algorithmic FLOPs of this launch (SURVEY.md Appendix A recipe) */
+  double bytes;      /* algorithmic bytes of this launch (same recipe) */
+} piper_hip_kernel_stat;
+int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, piper_hip_kernel_stat* out, int max_entries,
+                            int* n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPER_HIP_H */

@@ -1,0 +1,182 @@
+// attention.hip — text-encoder relative-position self-attention core, one launch per layer.
+//
+//   scores[i][j] = (q_i/√d)·k_j + (q_i/√d)·E_k[j−i+w]   (second term only for |j−i| ≤ w)
+//   p = softmax_j(scores);   out_i = Σ_j p[i][j]·v_j + Σ_{|δ|≤w} p[i][i+δ]·E_v[δ+w]
+//
+// This is exactly what the exported graph computes with MatMul + Pad/Reshape/Slice "skew" + Softmax
+// (GraphExecutor.swift:1862-1929, 1180-1210, 1371-1426): rel→abs maps relative column m of row i to absolute
+// column j = i + m − (T−1), abs→rel is its inverse, and the embedding table padded to 2T−1 rows is zero outside
+// the ±w window — so the skew is pure index arithmetic and the [N,H,T,2T−1] tensors never exist.
+// A block owns R query rows of one head; the R×T score strip lives in LDS (T ≤ 4096: the reference's own
+// --max-phonemes cap, PiperCLI.swift:394).
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int R = 8;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, const float* __restrict__ ek,
+                                                               const float* __restrict__ ev, float* __restrict__ out, int H, int d,
+                                                               int T, int w, int64_t in_batch_stride, int64_t out_batch_stride,
+                                                               int G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int W = 2 * w + 1;
+  float* qs = smem;              // [R][d]
+  float* qe = qs + R * d;        // [R][W]
+  float* part = qe + R * W;      // [G][R][d]
+  float* sc = part + G * R * d;  // [R][T]
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * R, h = blockIdx.y, n = blockIdx.z;
+  const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
+  const float* kb = k + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
+  const float* vb = v + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
+  const float scale = sqrtf((float)d);
+
+  // 1. q strip, scaled by Div like the graph (query / sqrt(k_channels))
+  for (int idx = tid; idx < R * d; idx += kBlock) {
+    const int c = idx / R, r = idx - c * R;
+    const int i = i0 + r;
+    qs[r * d + c] = i < T ? qb[(int64_t)c * T + i] / scale : 0.0f;
+  }
+  __syncthreads();
+  // 1b. relative-key logits for the ±w window
+  for (int idx = tid; idx < R * W; idx += kBlock) {
+    const int r = idx / W, m = idx - r * W;
+    float s = 0.0f;
+    for (int c = 0; c < d; c++) s += qs[r * d + c] * ek[m * d + c];
+    qe[r * W + m] = s;
+  }
+  __syncthreads();
+  // 2. score strip: lanes along j (k rows are read coalesced), R rows per thread in registers
+  for (int j = tid; j < T; j += kBlock) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    for (int c = 0; c < d; c++) {
+      const float kv = kb[(int64_t)c * T + j];
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = fmaf(qs[r * d + c], kv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int delta = j - (i0 + r);
+      float s = acc[r];
+      if (delta >= -w && delta <= w) s += qe[r * W + delta + w];
+      sc[r * T + j] = s;
+    }
+  }
+  __syncthreads();
+  // 3. row softmax (softmax.metal:13-41: max, exp, sum, multiply by 1/sum), one wave per row
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int r = wv; r < R; r += kBlock / 64) {
+      float* row = sc + r * T;
+      float m = -INFINITY;
+      for (int j = lane; j < T; j += 64) m = fmaxf(m, row[j]);
+      m = wave_max(m);
+      float s = 0.0f;
+      for (int j = lane; j < T; j += 64) {
+        const float e = expf(row[j] - m);
+        row[j] = e;
+        s += e;
+      }
+      s = wave_sum(s);
+      const float inv = 1.0f / s;
+      for (int j = lane; j < T; j += 64) row[j] *= inv;
+    }
+  }
+  __syncthreads();
+  // 4. P·V: thread = (channel c, key slice g); p comes from LDS as a broadcast
+  {
+    const int c = tid % d, g = tid / d;
+    if (g < G) {
+      const int j0 = (int)((int64_t)T * g / G), j1 = (int)((int64_t)T * (g + 1) / G);
+      float acc[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) acc[r] = 0.0f;
+      const float* vr = vb + (int64_t)c * T;
+      for (int j = j0; j < j1; j++) {
+        const float vv = vr[j];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = fmaf(sc[r * T + j], vv, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) part[(g * R + r) * d + c] = acc[r];
+    }
+  }
+  __syncthreads();
+  // 5. combine slices, add the relative-value term, store [H·d, T]
+  float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * d * T;
+  for (int idx = tid; idx < R * d; idx += kBlock) {
+    const int c = idx / R, r = idx - c * R;
+    const int i = i0 + r;
+    if (i >= T) continue;
+    float o = 0.0f;
+    for (int g = 0; g < G; g++) o += part[(g * R + r) * d + c];
+    float rel = 0.0f;
+    for (int m = 0; m < W; m++) {
+      const int j = i + m - w;
+      if (j >= 0 && j < T) rel = fmaf(sc[r * T + j], ev[m * d + c], rel);
+    }
+    ob[(int64_t)c * T + i] = o + rel;
+  }
+}
+
+}  // namespace
+
+namespace ph {
+int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
+                         const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
+                         int64_t out_batch_stride) {
+  if (N <= 0 || T <= 0) return PIPER_HIP_OK;
+  if (d > kBlock) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: head_dim %d > %d", d, kBlock);
+  if (T > 4096) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: T=%d exceeds 4096 (reference max-phonemes cap)", T);
+  if (H > 65535 || N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: heads/batch too large");
+  const int G = kBlock / d;
+  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)R * T) * sizeof(float);
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute((const void*)rel_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    configured = lds;
+  }
+  dim3 grid((unsigned)ceil_div(T, R), (unsigned)H, (unsigned)N);
+  hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
+                     out_batch_stride, G);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention launch failed: %s", hipGetErrorString(e));
+  return PIPER_HIP_OK;
+}
+}  // namespace ph
+
+PH_EXPORT int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, const float* k, const float* v,
+                                          const float* emb_rel_k, const float* emb_rel_v, int64_t n, int64_t heads,
+                                          int64_t head_dim, int64_t t, int64_t window, float** out, piper_hip_stream stream) {
+  PH_CHECK_CTX(ctx);
+  if (n < 0 || heads <= 0 || head_dim <= 0 || t < 0 || window < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: bad shape");
+  if (n * heads * head_dim * t > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: tensor too large");
+  const size_t cnt = (size_t)(n * heads * head_dim * t);
+  int rc = ph::ensure_out(ctx, out, cnt, 0);
+  if (rc) return rc;
+  if (cnt == 0) return PIPER_HIP_OK;
+  if (!q || !k || !v || !emb_rel_k || !emb_rel_v) PH_FAIL(PIPER_HIP_ERR_ARG, "rel_attention: null input");
+  ph::StreamScope ss(ctx, stream);
+  const int64_t bs = heads * head_dim * t;
+  rc = ph::launch_rel_attention(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, *out, (int)n, (int)heads, (int)head_dim, (int)t,
+                                (int)window, bs, bs);
+  if (rc) return rc;
+  return ss.finish("rel_attention_f32");
+}

@@ -1,0 +1,108 @@
+// common.h — internals shared by the piper_hip translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/piper_hip.h"
+
+#define PH_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace ph {
+
+// thread-local error text behind piper_hip_last_error()
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define PH_FAIL(code, ...)        \
+  do {                            \
+    ph::set_error(__VA_ARGS__);   \
+    return (code);                \
+  } while (0)
+
+#define PH_HIP(expr, code)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) PH_FAIL(code, "%s failed: %s", #expr, hipGetErrorString(_e));       \
+  } while (0)
+
+#define PH_CHECK_CTX(ctx)                                      \
+  do {                                                         \
+    if (!(ctx)) PH_FAIL(PIPER_HIP_ERR_ARG, "null context");    \
+  } while (0)
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Size-bucketed caching device allocator: the reference allocates a fresh MTLBuffer per op output
+// (MetalBackend.swift:1184); here alloc/free recycle blocks so op-level callers never hit hipMalloc in
+// steady state. Blocks are rounded up to a power of two ≥ 256 B.
+struct Pool {
+  std::mutex mu;
+  std::unordered_map<void*, size_t> live;            // ptr -> bucket bytes
+  std::map<size_t, std::vector<void*>> free_blocks;  // bucket bytes -> ptrs
+  size_t bytes_reserved = 0;
+  int alloc(size_t bytes, void** out);
+  int release(void* p);  // returns PIPER_HIP_ERR_ARG if p is not a live pool block
+  void trim();
+};
+
+}  // namespace ph
+
+struct piper_hip_ctx {
+  int device = 0;
+  hipDeviceProp_t props{};
+  hipStream_t default_stream = nullptr;  // used when the caller passes stream == NULL (blocking semantics)
+  ph::Pool pool;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  int num_cus = 256;
+  // op-internal temporaries (packed weights, fused-op intermediates) of non-blocking calls: returned to the pool at
+  // the next host-visible sync point of this context
+  std::vector<void*> deferred;
+};
+
+namespace ph {
+
+void release_deferred(piper_hip_ctx* ctx);
+inline void defer_free(piper_hip_ctx* ctx, void* p) {
+  if (p) ctx->deferred.push_back(p);
+}
+
+// Resolve the stream argument of an op entry point: NULL ⇒ ctx default stream + block at the end.
+struct StreamScope {
+  piper_hip_ctx* ctx;
+  hipStream_t s;
+  bool blocking;
+  StreamScope(piper_hip_ctx* c, piper_hip_stream user) : ctx(c) {
+    blocking = (user == nullptr);
+    s = blocking ? c->default_stream : (hipStream_t)user;
+  }
+  // call at the end of an op: surfaces launch errors, and blocks when commandBuffer == nil semantics apply
+  int finish(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    if (blocking) {
+      e = hipStreamSynchronize(s);
+      if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "%s: execution failed: %s", what, hipGetErrorString(e));
+      if (!ctx->deferred.empty()) {
+        // temporaries of earlier non-blocking calls may live on other streams of this context
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "%s: device sync failed: %s", what, hipGetErrorString(e));
+        release_deferred(ctx);
+      }
+    }
+    return PIPER_HIP_OK;
+  }
+};
+
+// Output-buffer convention: *out == NULL ⇒ allocate `count` floats from the pool (≥ 1 byte like allocateBuffer).
+int ensure_out(piper_hip_ctx* ctx, float** out, size_t count, int alloc_err_code_note);
+
+}  // namespace ph

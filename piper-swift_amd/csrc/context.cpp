@@ -1,0 +1,241 @@
+// context.cpp — device context, pooled buffers, transfers, streams, timers.
+// Replaces Metal/MetalContext.swift:4-62 and the buffer/blit helpers of MetalBackend.swift:34-66, 841-874, 963-993.
+#include "common.h"
+
+namespace ph {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+static size_t bucket_of(size_t bytes) {
+  size_t b = 256;
+  while (b < bytes) b <<= 1;
+  return b;
+}
+
+int Pool::alloc(size_t bytes, void** out) {
+  const size_t b = bucket_of(bytes < 1 ? 1 : bytes);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = free_blocks.find(b);
+  if (it != free_blocks.end() && !it->second.empty()) {
+    *out = it->second.back();
+    it->second.pop_back();
+    live[*out] = b;
+    return PIPER_HIP_OK;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, b);
+  if (e != hipSuccess) {
+    // give cached blocks back to the driver and retry once
+    for (auto& kv : free_blocks) {
+      for (void* q : kv.second) (void)hipFree(q);
+      bytes_reserved -= kv.first * kv.second.size();
+      kv.second.clear();
+    }
+    e = hipMalloc(&p, b);
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_ALLOC, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
+  }
+  bytes_reserved += b;
+  live[p] = b;
+  *out = p;
+  return PIPER_HIP_OK;
+}
+
+int Pool::release(void* p) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = live.find(p);
+  if (it == live.end()) PH_FAIL(PIPER_HIP_ERR_ARG, "piper_hip_free: %p is not a live buffer of this context", p);
+  free_blocks[it->second].push_back(p);
+  live.erase(it);
+  return PIPER_HIP_OK;
+}
+
+void Pool::trim() {
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& kv : free_blocks)
+    for (void* q : kv.second) (void)hipFree(q);
+  free_blocks.clear();
+  for (auto& kv : live) (void)hipFree(kv.first);
+  live.clear();
+  bytes_reserved = 0;
+}
+
+void release_deferred(piper_hip_ctx* ctx) {
+  for (void* p : ctx->deferred) (void)ctx->pool.release(p);
+  ctx->deferred.clear();
+}
+
+int ensure_out(piper_hip_ctx* ctx, float** out, size_t count, int) {
+  if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "null output pointer");
+  if (*out) return PIPER_HIP_OK;
+  void* p = nullptr;
+  int rc = ctx->pool.alloc(count * sizeof(float), &p);
+  if (rc) return rc;
+  *out = (float*)p;
+  return PIPER_HIP_OK;
+}
+
+}  // namespace ph
+
+PH_EXPORT const char* piper_hip_last_error(void) { return ph::get_error(); }
+PH_EXPORT int piper_hip_abi_version(void) { return PIPER_HIP_ABI_VERSION; }
+
+PH_EXPORT int piper_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+PH_EXPORT int piper_hip_create(int device, piper_hip_ctx** out) {
+  if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "null out");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "no HIP device available (%s); this backend has no CPU fallback",
+            e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  }
+  if (device < 0 || device >= n) PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "device %d out of range (have %d)", device, n);
+  PH_HIP(hipSetDevice(device), PIPER_HIP_ERR_UNAVAILABLE);
+  piper_hip_ctx* c = new piper_hip_ctx();
+  c->device = device;
+  if (hipGetDeviceProperties(&c->props, device) != hipSuccess) {
+    delete c;
+    PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "hipGetDeviceProperties failed");
+  }
+  // The code objects in this library are gfx950 only (no multi-arch dispatch).
+  if (strncmp(c->props.gcnArchName, "gfx950", 6) != 0) {
+    std::string arch = c->props.gcnArchName;
+    delete c;
+    PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "device %d is %s; this library ships gfx950 (MI355X) code only", device,
+            arch.c_str());
+  }
+  c->num_cus = c->props.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->default_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+    delete c;
+    PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "stream/event creation failed");
+  }
+  *out = c;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT void piper_hip_destroy(piper_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ph::release_deferred(ctx);
+  ctx->pool.trim();
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->default_stream) (void)hipStreamDestroy(ctx->default_stream);
+  delete ctx;
+}
+
+PH_EXPORT int piper_hip_alloc(piper_hip_ctx* ctx, size_t bytes, void** out) {
+  PH_CHECK_CTX(ctx);
+  if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "null out");
+  return ctx->pool.alloc(bytes, out);
+}
+
+PH_EXPORT int piper_hip_free(piper_hip_ctx* ctx, void* buf) {
+  PH_CHECK_CTX(ctx);
+  if (!buf) return PIPER_HIP_OK;
+  return ctx->pool.release(buf);
+}
+
+PH_EXPORT int piper_hip_upload_f32(piper_hip_ctx* ctx, const float* host, size_t count, float** out) {
+  PH_CHECK_CTX(ctx);
+  if (!out || (!host && count)) PH_FAIL(PIPER_HIP_ERR_ARG, "null pointer");
+  void* p = nullptr;
+  int rc = ctx->pool.alloc(count * sizeof(float), &p);
+  if (rc) return rc;
+  if (count) {
+    // ordered after everything already enqueued on the default stream; blocks like uploadFloat32
+    hipError_t e = hipMemcpyAsync(p, host, count * sizeof(float), hipMemcpyHostToDevice, ctx->default_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->default_stream);
+    if (e != hipSuccess) {
+      ctx->pool.release(p);
+      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = (float*)p;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_upload_i64(piper_hip_ctx* ctx, const int64_t* host, size_t count, int64_t** out) {
+  PH_CHECK_CTX(ctx);
+  if (!out || (!host && count)) PH_FAIL(PIPER_HIP_ERR_ARG, "null pointer");
+  void* p = nullptr;
+  int rc = ctx->pool.alloc(count * sizeof(int64_t), &p);
+  if (rc) return rc;
+  if (count) {
+    hipError_t e = hipMemcpyAsync(p, host, count * sizeof(int64_t), hipMemcpyHostToDevice, ctx->default_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->default_stream);
+    if (e != hipSuccess) {
+      ctx->pool.release(p);
+      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "upload failed: %s", hipGetErrorString(e));
+    }
+  }
+  *out = (int64_t*)p;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_download_f32(piper_hip_ctx* ctx, const float* buf, float* host, size_t count) {
+  PH_CHECK_CTX(ctx);
+  if ((!buf || !host) && count) PH_FAIL(PIPER_HIP_ERR_ARG, "null pointer");
+  // downloadFloat32 is a full sync point in the reference ("hydration", GraphExecutor.swift:408-467)
+  PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);
+  ph::release_deferred(ctx);
+  if (count) PH_HIP(hipMemcpy(host, buf, count * sizeof(float), hipMemcpyDeviceToHost), PIPER_HIP_ERR_LAUNCH);
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_stream_create(piper_hip_ctx* ctx, piper_hip_stream* out) {
+  PH_CHECK_CTX(ctx);
+  if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "null out");
+  hipStream_t s;
+  PH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
+  *out = (piper_hip_stream)s;
+  return PIPER_HIP_OK;
+}
+PH_EXPORT int piper_hip_stream_destroy(piper_hip_ctx* ctx, piper_hip_stream s) {
+  PH_CHECK_CTX(ctx);
+  if (s) PH_HIP(hipStreamDestroy((hipStream_t)s), PIPER_HIP_ERR_LAUNCH);
+  return PIPER_HIP_OK;
+}
+PH_EXPORT int piper_hip_stream_sync(piper_hip_ctx* ctx, piper_hip_stream s) {
+  PH_CHECK_CTX(ctx);
+  // temporaries may have been used on any stream of this context: make them all quiescent before recycling
+  PH_HIP(hipStreamSynchronize(s ? (hipStream_t)s : ctx->default_stream), PIPER_HIP_ERR_LAUNCH);
+  if (!ctx->deferred.empty()) {
+    PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);
+    ph::release_deferred(ctx);
+  }
+  return PIPER_HIP_OK;
+}
+PH_EXPORT int piper_hip_timer_begin(piper_hip_ctx* ctx, piper_hip_stream s) {
+  PH_CHECK_CTX(ctx);
+  PH_HIP(hipEventRecord(ctx->t0, s ? (hipStream_t)s : ctx->default_stream), PIPER_HIP_ERR_LAUNCH);
+  return PIPER_HIP_OK;
+}
+PH_EXPORT int piper_hip_timer_end(piper_hip_ctx* ctx, piper_hip_stream s, double* gpu_ms) {
+  PH_CHECK_CTX(ctx);
+  PH_HIP(hipEventRecord(ctx->t1, s ? (hipStream_t)s : ctx->default_stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipEventSynchronize(ctx->t1), PIPER_HIP_ERR_LAUNCH);
+  float ms = 0;
+  PH_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1), PIPER_HIP_ERR_LAUNCH);
+  if (gpu_ms) *gpu_ms = ms;
+  return PIPER_HIP_OK;
+}

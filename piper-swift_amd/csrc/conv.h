@@ -1,0 +1,74 @@
+// conv.h — internal interface of the Conv1d / ConvTranspose1d kernel family (conv.hip).
+#pragma once
+#include "common.h"
+
+namespace ph {
+
+// input transform applied while the B operand (activations) is loaded
+enum Prologue : int {
+  PRO_NONE = 0,
+  PRO_LRELU = 1,       // x = lrelu(x, alpha)
+  PRO_AVG3_LRELU = 2,  // x = lrelu(((x + x2) + x3) / 3, alpha)   (HiFi-GAN MRF mean folded into the consumer)
+};
+
+// output transform / routing applied to the accumulator tile
+enum Epilogue : int {
+  EPI_STORE = 0,        // y = v (+ res)                         v = bias + conv
+  EPI_RELU = 1,         // y = relu(v)
+  EPI_TANH = 2,         // y = tanh(v)
+  EPI_RSUB = 3,         // y = res − v                           (flow coupling reverse: x1 − m)
+  EPI_WN_RES_SKIP = 4,  // co <  wn_c: y[co] = res[co] + v ; co ≥ wn_c: y2[co−wn_c] = (skip? skip[..]:0) + v
+  EPI_WN_SKIP_LAST = 5, // y2[co] = (skip? skip[co]:0) + v
+  EPI_CONVT = 6,        // rows are (co, phase): y[co][q·s + phase − padL] = v
+};
+
+struct ConvArgs {
+  // tensors
+  const float* x = nullptr;   // [N, x_channels, Lin]
+  const float* x2 = nullptr;  // PRO_AVG3_LRELU
+  const float* x3 = nullptr;
+  const float* w = nullptr;   // MFMA path: packed fragments (pack_conv_weights); direct path: raw ONNX layout
+  const float* bias = nullptr;
+  const float* res = nullptr;   // residual / minuend, same addressing as y
+  const float* skip = nullptr;  // EPI_WN_*: running skip sum, same addressing as y2 (may be null)
+  float* y = nullptr;
+  float* y2 = nullptr;
+  // geometry
+  int N = 1, Cin = 0, Cout = 0, K = 1, dil = 1, padL = 0, Lin = 0, Lout = 0;
+  int stride = 1, groups = 1;  // direct path only
+  int64_t x_batch_stride = 0;  // floats between batch items of x (x2/x3 share it)
+  int64_t y_batch_stride = 0;  // floats between batch items of y / res
+  int64_t y2_batch_stride = 0;
+  int in_ch_base = 0, in_ch_sign = 1;    // physical input channel = in_ch_base + in_ch_sign·ci  (folds Flip/Split)
+  int out_ch_base = 0, out_ch_sign = 1;  // physical output channel of y/res = out_ch_base + out_ch_sign·co
+  int y_len = 0;                         // row length of y/res/y2/skip (floats)
+  int prologue = PRO_NONE;
+  float alpha = 0.0f;
+  int epilogue = EPI_STORE;
+  int gate = 0;  // MFMA path: Cout = 2·H rows; emits H rows tanh(a)·sigmoid(b)
+  int wn_c = 0;  // EPI_WN_RES_SKIP split point
+  // ConvTranspose (EPI_CONVT): GEMM rows = Cout_ct·ct_stride, GEMM cols = q
+  int ct_stride = 0, ct_padL = 0, ct_Lout = 0;
+};
+
+// number of floats of the packed fragment image for a [Cout, Cin, K] conv
+size_t packed_conv_floats(int Cout, int Cin, int K);
+// ConvTranspose [Cin, Cout, K] stride s → rows Cout·s, taps ceil(K/s)
+size_t packed_convt_floats(int Cin, int Cout, int K, int s);
+int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
+int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed);
+
+// true when the MFMA implicit-GEMM path can run this geometry
+bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups);
+// Enqueue one conv on `s`. args.w must already be packed for the MFMA path.
+int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
+// Thread-per-output kernel for everything else (groups, stride, tiny Cout). args.w is raw [Cout, Cin/g, K].
+int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
+// Thread-per-output ConvTranspose for geometries the phase decomposition does not cover. w raw [Cin, Cout/g, K].
+int launch_convt_direct(piper_hip_ctx* ctx, hipStream_t s, const float* x, const float* w, const float* bias, float* y, int N,
+                        int Cin, int Lin, int Cout, int K, int stride, int dil, int padL, int Lout, int groups);
+
+// algorithmic work of one conv (SURVEY.md Appendix A recipe)
+inline double conv_flops(int Cout, int Cin_per_g, int K, int64_t Lout) { return 2.0 * Cout * (double)Lout * Cin_per_g * K; }
+
+}  // namespace ph

@@ -1,0 +1,847 @@
+// voice.hip — whole-utterance VITS forward pass as a static schedule of fused launches, replayed as a HIP graph.
+//
+// Stands where PiperMetalRuntime.synthesize → GraphExecutor.executeOutput stands in the reference
+// (PiperMetalRuntime.swift:62-80, GraphExecutor.swift:156-327), but instead of interpreting 2 755 ONNX nodes with a
+// fresh buffer, a string-keyed table lookup and (in the unbatched mode) a blocking commit per node, the voice is
+// compiled once into ≈110 launches over a preplanned arena:
+//   encoder layer = qkv conv · rel-attention · o conv · add+LayerNorm · ffn1(+ReLU) · ffn2 · add+LayerNorm
+//   flow coupling = pre conv (Flip/Split folded into channel maps) · 4×[in conv + tanh·sigmoid gate, res/skip conv
+//                   writing x and skip in place] · post conv with x1 ← x1 − m in place (Concat folded)
+//   generator     = conv_pre · per stage [LeakyReLU(+MRF mean)→ConvTranspose, 3 ResBlocks with LeakyReLU and residual
+//                   fused into each conv] · LeakyReLU+MRF mean→conv_post→tanh
+// Weights stay resident (packed once into MFMA fragment order); nothing is decoded or uploaded per call
+// (the reference re-decodes 401 initializers and re-uploads every Conv weight per synthesize: GraphExecutor.swift:187-189,
+// 1774-1780).  Utterances are independent, so a voice has several slots (stream + arena + graph) that overlap on the GPU.
+#include <cmath>
+#include <functional>
+#include <memory>
+
+#include "../../include/piper_hip_voice_layout.h"
+#include "conv.h"
+
+namespace ph {
+int validate_config(const piper_hip_voice_config* c);
+int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
+                         const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
+                         int64_t out_batch_stride);
+}  // namespace ph
+
+using namespace ph;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxSlots = 16;
+
+// x[c][t] = emb[ids[t]][c] * sqrt(H): Gather + Mul + Transpose of the graph head (GraphExecutor.swift:653-666)
+__global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
+                                                       float* __restrict__ x, int H, int T, int n_vocab, float scale) {
+  const int total = H * T;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
+    const int c = i / T, t = i - c * T;
+    int64_t id = ids[t];
+    if (id < 0 || id >= n_vocab) id = 0;  // gather.metal: OOB index → row 0
+    x[i] = emb[id * H + c] * scale;
+  }
+}
+
+// z_p[c][f] = m_p[c][t(f)] + (noise[c][f] * exp(logs_p[c][t(f)])) * noise_scale.
+// m_p/logs_p expansion by the one-hot path matrix (MatMul [1,F,T]×[1,T,I], GraphExecutor.swift:1862-1915) is a row
+// gather: frame f copies phoneme t(f); bit-identical to the matmul (every other product is an exact ±0 add).
+__global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __restrict__ stats, const int32_t* __restrict__ frame2id,
+                                                              const float* __restrict__ noise, float* __restrict__ zp, int I, int T,
+                                                              int F, const float* __restrict__ noise_scale_dev) {
+  const float noise_scale = noise_scale_dev[0];  // per-utterance scalar lives in device memory so a replayed graph sees it
+  const int64_t total = (int64_t)I * F;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int c = (int)(i / F), f = (int)(i - (int64_t)c * F);
+    const int t = frame2id[f];
+    const float m = stats[(int64_t)c * T + t];
+    const float lg = stats[(int64_t)(I + c) * T + t];
+    const float nz = noise[i];
+    zp[i] = m + (nz * expf(lg)) * noise_scale;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void flip_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L) {
+  const int64_t total = (int64_t)C * L;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int c = (int)(i / L), l = (int)(i - (int64_t)c * L);
+    y[i] = x[(int64_t)(C - 1 - c) * L + l];
+  }
+}
+
+struct Step {
+  std::string name;
+  std::function<int(hipStream_t)> run;
+  double flops = 0, bytes = 0;
+};
+
+struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bias pointer into the resident blob
+  const float* w = nullptr;
+  const float* bias = nullptr;
+  int Cout = 0, Cin = 0, K = 1;
+  bool mfma = false;
+};
+
+struct Slot {
+  bool inited = false;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int T = -1, F = -1;
+  // device buffers
+  std::vector<void*> owned;
+  int64_t* ids = nullptr;
+  int32_t* frame2id = nullptr;
+  float* noise = nullptr;
+  float* noise_scale = nullptr;  // [1] device
+  float h_noise_scale = 0.f;
+  float* audio = nullptr;
+  int64_t n_samples = 0;
+  std::vector<Step> steps;
+  std::map<std::string, std::pair<const float*, size_t>> taps;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  bool timed = false;
+  // host staging (pinned so the H2D copies are truly async)
+  int64_t* h_ids = nullptr;
+  int32_t* h_f2i = nullptr;
+  size_t h_cap_t = 0, h_cap_f = 0;
+};
+
+}  // namespace
+
+struct piper_hip_voice {
+  piper_hip_ctx* ctx = nullptr;
+  piper_hip_voice_config cfg{};
+  float* blob = nullptr;    // resident copy of the fp32 blob (biases, embeddings, LayerNorm, raw weights)
+  float* packed = nullptr;  // MFMA fragment images
+  size_t blob_floats = 0, packed_floats = 0;
+  std::map<std::string, piper_tensor_desc> index;
+  // compiled weights
+  struct EncLayer {
+    ConvW qkv, o, f1, f2;
+    const float *ek, *ev, *g1, *b1, *g2, *b2;
+    float* qkv_bias;
+  };
+  std::vector<EncLayer> enc;
+  ConvW proj;
+  struct Coupling {
+    ConvW pre, post;
+    std::vector<ConvW> in, rs;
+  };
+  std::vector<Coupling> flows;
+  ConvW conv_pre, conv_post;
+  struct Stage {
+    ConvW up;  // packed ConvTranspose (rows = Cout·stride)
+    int Cin, Cout, K, stride, pad;
+    std::vector<std::vector<ConvW>> rb;  // [n_rb][n_dil or 2·n_dil]
+  };
+  std::vector<Stage> stages;
+  std::vector<void*> owned;
+  Slot slots[kMaxSlots];
+  int hop = 1;
+};
+
+namespace {
+
+struct IndexOut {
+  std::map<std::string, piper_tensor_desc>* m;
+};
+void index_visit(const piper_tensor_desc* d, void* user) { (*((IndexOut*)user)->m)[d->name] = *d; }
+
+const float* tensor(const piper_hip_voice* v, const std::string& name) {
+  auto it = v->index.find(name);
+  if (it == v->index.end()) return nullptr;
+  return v->blob + it->second.offset;
+}
+
+struct Packer {  // bump allocator over the packed-weights allocation
+  piper_hip_voice* v;
+  size_t off = 0;
+  hipStream_t s;
+  float* take(size_t n) {
+    float* p = v->packed ? v->packed + off : nullptr;
+    off += (n + 63) & ~(size_t)63;
+    return p;
+  }
+};
+
+// Registers one conv. dry = true only measures the packed size.
+ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true) {
+  ConvW c;
+  c.Cout = Cout; c.Cin = Cin; c.K = K;
+  c.mfma = conv_mfma_eligible(Cout, Cin, K, 1, 1);
+  const float* w = dry ? nullptr : tensor(pk.v, prefix + ".weight");
+  c.bias = (dry || !has_bias) ? nullptr : tensor(pk.v, prefix + ".bias");
+  if (c.mfma) {
+    float* p = pk.take(packed_conv_floats(Cout, Cin, K));
+    if (!dry) pack_conv_weights(pk.s, w, Cout, Cin, K, p);
+    c.w = p;
+  } else {
+    c.w = w;
+  }
+  return c;
+}
+
+int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<float*>* qkv_bias) {
+  const piper_hip_voice_config& c = v->cfg;
+  const int H = c.hidden, I = c.inter;
+  char nm[128];
+  v->enc.clear(); v->flows.clear(); v->stages.clear();
+  for (int l = 0; l < c.n_layers; l++) {
+    piper_hip_voice::EncLayer L{};
+    L.qkv_bias = qkv_bias ? (*qkv_bias)[l] : nullptr;
+    // q,k,v as one 3H-row conv: the packed image is [row tile][step][64], so three H-row images concatenate
+    L.qkv.Cout = 3 * H; L.qkv.Cin = H; L.qkv.K = 1; L.qkv.mfma = true;
+    float* p = pk.take(3 * packed_conv_floats(H, H, 1));
+    L.qkv.w = p;
+    if (!dry) {
+      static const char* qkv[3] = {"conv_q", "conv_k", "conv_v"};
+      for (int j = 0; j < 3; j++) {
+        snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.%s", l, qkv[j]);
+        pack_conv_weights(pk.s, tensor(v, std::string(nm) + ".weight"), H, H, 1, p + j * packed_conv_floats(H, H, 1));
+        PH_HIP(hipMemcpyAsync(L.qkv_bias + j * H, tensor(v, std::string(nm) + ".bias"), H * sizeof(float),
+                              hipMemcpyDeviceToDevice, pk.s), PIPER_HIP_ERR_LAUNCH);
+      }
+      L.qkv.bias = L.qkv_bias;
+    }
+    snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.conv_o", l);
+    L.o = make_conv(pk, dry, nm, H, H, 1);
+    snprintf(nm, sizeof nm, "enc_p.encoder.ffn_layers.%d.conv_1", l);
+    L.f1 = make_conv(pk, dry, nm, c.ffn, H, c.ffn_kernel);
+    snprintf(nm, sizeof nm, "enc_p.encoder.ffn_layers.%d.conv_2", l);
+    L.f2 = make_conv(pk, dry, nm, H, c.ffn, c.ffn_kernel);
+    if (!dry) {
+      snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.emb_rel_k", l); L.ek = tensor(v, nm);
+      snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.emb_rel_v", l); L.ev = tensor(v, nm);
+      snprintf(nm, sizeof nm, "enc_p.encoder.norm_layers_1.%d.gamma", l); L.g1 = tensor(v, nm);
+      snprintf(nm, sizeof nm, "enc_p.encoder.norm_layers_1.%d.beta", l); L.b1 = tensor(v, nm);
+      snprintf(nm, sizeof nm, "enc_p.encoder.norm_layers_2.%d.gamma", l); L.g2 = tensor(v, nm);
+      snprintf(nm, sizeof nm, "enc_p.encoder.norm_layers_2.%d.beta", l); L.b2 = tensor(v, nm);
+    }
+    v->enc.push_back(L);
+  }
+  v->proj = make_conv(pk, dry, "enc_p.proj", 2 * I, H, 1);
+  for (int f = 0; f < c.n_flows; f++) {
+    piper_hip_voice::Coupling C;
+    snprintf(nm, sizeof nm, "flow.flows.%d.pre", 2 * f);
+    C.pre = make_conv(pk, dry, nm, H, I / 2, 1);
+    for (int i = 0; i < c.wn_layers; i++) {
+      snprintf(nm, sizeof nm, "flow.flows.%d.enc.in_layers.%d", 2 * f, i);
+      C.in.push_back(make_conv(pk, dry, nm, 2 * H, H, c.wn_kernel));
+      snprintf(nm, sizeof nm, "flow.flows.%d.enc.res_skip_layers.%d", 2 * f, i);
+      C.rs.push_back(make_conv(pk, dry, nm, (i + 1 < c.wn_layers) ? 2 * H : H, H, 1));
+    }
+    snprintf(nm, sizeof nm, "flow.flows.%d.post", 2 * f);
+    C.post = make_conv(pk, dry, nm, I / 2, H, 1);
+    v->flows.push_back(C);
+  }
+  v->conv_pre = make_conv(pk, dry, "dec.conv_pre", c.up_initial, I, 7);
+  int ch = c.up_initial;
+  for (int u = 0; u < c.n_ups; u++) {
+    piper_hip_voice::Stage S;
+    S.Cin = ch; S.Cout = ch / 2; S.K = c.up_kernels[u]; S.stride = c.up_rates[u]; S.pad = (S.K - S.stride) / 2;
+    const int J = (S.K + S.stride - 1) / S.stride;
+    S.up.Cout = S.Cout * S.stride; S.up.Cin = S.Cin; S.up.K = J; S.up.mfma = true;
+    float* p = pk.take(packed_convt_floats(S.Cin, S.Cout, S.K, S.stride));
+    S.up.w = p;
+    if (!dry) {
+      snprintf(nm, sizeof nm, "dec.ups.%d", u);
+      pack_convt_weights(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, p);
+      S.up.bias = tensor(v, std::string(nm) + ".bias");
+    }
+    ch /= 2;
+    for (int j = 0; j < c.n_rb; j++) {
+      std::vector<ConvW> convs;
+      const int rb = u * c.n_rb + j;
+      for (int d = 0; d < c.rb_n_dil; d++) {
+        if (c.resblock_type == 1) {
+          snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", rb, d);
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+          snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", rb, d);
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+        } else {
+          snprintf(nm, sizeof nm, "dec.resblocks.%d.convs.%d", rb, d);
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+        }
+      }
+      S.rb.push_back(convs);
+    }
+    v->stages.push_back(S);
+  }
+  v->conv_post = make_conv(pk, dry, "dec.conv_post", 1, ch, 7, false);
+  return PIPER_HIP_OK;
+}
+
+void slot_release(piper_hip_voice* v, Slot& s, bool all) {
+  if (s.exec) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
+  if (s.graph) { (void)hipGraphDestroy(s.graph); s.graph = nullptr; }
+  for (void* p : s.owned) (void)v->ctx->pool.release(p);
+  s.owned.clear();
+  s.steps.clear();
+  s.taps.clear();
+  s.T = s.F = -1;
+  if (all && s.inited) {
+    if (s.h_ids) (void)hipHostFree(s.h_ids);
+    if (s.h_f2i) (void)hipHostFree(s.h_f2i);
+    s.h_ids = nullptr; s.h_f2i = nullptr; s.h_cap_t = s.h_cap_f = 0;
+    if (s.ev0) (void)hipEventDestroy(s.ev0);
+    if (s.ev1) (void)hipEventDestroy(s.ev1);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s.inited = false;
+  }
+}
+
+struct Arena {
+  piper_hip_voice* v;
+  Slot* s;
+  int rc = PIPER_HIP_OK;
+  float* f32(size_t n) {
+    void* p = nullptr;
+    if (rc) return nullptr;
+    rc = v->ctx->pool.alloc((n ? n : 1) * sizeof(float), &p);
+    if (!rc) s->owned.push_back(p);
+    return (float*)p;
+  }
+  void* raw(size_t bytes) {
+    void* p = nullptr;
+    if (rc) return nullptr;
+    rc = v->ctx->pool.alloc(bytes ? bytes : 1, &p);
+    if (!rc) s->owned.push_back(p);
+    return p;
+  }
+};
+
+double conv_bytes(int Cin, int Cout, int K, int64_t L) { return 4.0 * ((double)Cin * L + (double)Cout * L + (double)Cout * Cin * K + Cout); }
+
+// conv step over a resident ConvW
+void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW& w, ConvArgs a, int64_t Lout_for_work) {
+  a.w = w.w;
+  a.bias = w.bias;
+  a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K;
+  piper_hip_ctx* ctx = v->ctx;
+  Step st;
+  st.name = name;
+  const bool mfma = w.mfma;
+  st.run = [ctx, a, mfma](hipStream_t q) { return mfma ? launch_conv_mfma(ctx, q, a) : launch_conv_direct(ctx, q, a); };
+  st.flops = conv_flops(w.Cout, w.Cin, w.K, Lout_for_work);
+  st.bytes = conv_bytes(w.Cin, a.gate ? w.Cout / 2 : w.Cout, w.K, Lout_for_work);
+  s.steps.push_back(std::move(st));
+}
+
+int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
+  const piper_hip_voice_config& c = v->cfg;
+  piper_hip_ctx* ctx = v->ctx;
+  const int H = c.hidden, I = c.inter, d = H / c.n_heads;
+  slot_release(v, s, false);
+  Arena ar{v, &s};
+  s.T = T; s.F = F;
+  s.ids = (int64_t*)ar.raw((size_t)T * sizeof(int64_t));
+  s.frame2id = (int32_t*)ar.raw((size_t)F * sizeof(int32_t));
+  s.noise = ar.f32((size_t)I * F);
+  s.noise_scale = ar.f32(1);
+  // ---------------- text encoder
+  float* x = ar.f32((size_t)H * T);
+  float* x1 = ar.f32((size_t)H * T);
+  float* qkv = ar.f32((size_t)3 * H * T);
+  float* att = ar.f32((size_t)H * T);
+  float* y = ar.f32((size_t)H * T);
+  float* ff = ar.f32((size_t)c.ffn * T);
+  float* stats = ar.f32((size_t)2 * I * T);
+  float* zp = ar.f32((size_t)I * F);
+  float* zflip = ar.f32((size_t)I * F);
+  float* h = ar.f32((size_t)H * F);
+  float* acts = ar.f32((size_t)H * F);
+  float* skip = ar.f32((size_t)H * F);
+  float* dec0 = ar.f32((size_t)c.up_initial * F);
+  if (ar.rc) return ar.rc;
+  {
+    Step st;
+    st.name = "embed";
+    const int64_t* ids = s.ids;
+    const float* emb = tensor(v, "enc_p.emb.weight");
+    const int nv = c.n_vocab;
+    const float scale = sqrtf((float)H);
+    st.run = [=](hipStream_t q) {
+      const int grid = (int)std::min<int64_t>(ceil_div((int64_t)H * T, kBlock), 2048);
+      hipLaunchKernelGGL(embed_kernel, dim3(grid), dim3(kBlock), 0, q, ids, emb, x, H, T, nv, scale);
+      return PIPER_HIP_OK;
+    };
+    s.steps.push_back(st);
+  }
+  auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L) {
+    ConvArgs a;
+    a.x = in; a.y = out; a.N = 1; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
+    a.y_len = L;
+    return a;
+  };
+  const int kf = c.ffn_kernel;
+  for (int l = 0; l < c.n_layers; l++) {
+    const auto& L = v->enc[l];
+    const std::string p = "enc" + std::to_string(l) + ".";
+    add_conv(v, s, p + "qkv", L.qkv, plain(x, qkv, H, 3 * H, T), T);
+    {
+      Step st;
+      st.name = p + "rel_attention";
+      const float *ek = L.ek, *ev = L.ev;
+      const int nh = c.n_heads, w = c.window;
+      st.run = [=](hipStream_t q) {
+        return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, 1, nh, d, T, w,
+                                    (int64_t)3 * H * T, (int64_t)H * T);
+      };
+      // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
+      st.flops = 2.0 * nh * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
+      st.bytes = 4.0 * nh * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
+      s.steps.push_back(st);
+    }
+    add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T), T);
+    auto add_ln = [&](const std::string& nm, const float* a, const float* b, const float* g, const float* be, float* out) {
+      Step st;
+      st.name = nm;
+      st.run = [=](hipStream_t q) {
+        float* o = out;
+        return piper_hip_add_layernorm_f32(ctx, a, b, g, be, 1, H, T, 1e-5f, &o, (piper_hip_stream)q);
+      };
+      s.steps.push_back(st);
+    };
+    add_ln(p + "add_ln1", x, y, L.g1, L.b1, x1);
+    {
+      ConvArgs a = plain(x1, ff, H, c.ffn, T);
+      a.padL = (kf - 1) / 2;
+      a.epilogue = EPI_RELU;
+      add_conv(v, s, p + "ffn1_relu", L.f1, a, T);
+      ConvArgs b = plain(ff, y, c.ffn, H, T);
+      b.padL = (kf - 1) / 2;
+      add_conv(v, s, p + "ffn2", L.f2, b, T);
+    }
+    add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
+  }
+  s.taps["enc_out"] = {x, (size_t)H * T};
+  add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T), T);
+  s.taps["m_p"] = {stats, (size_t)I * T};
+  s.taps["logs_p"] = {stats + (size_t)I * T, (size_t)I * T};
+  {
+    Step st;
+    st.name = "expand_noise";
+    const int32_t* f2i = s.frame2id;
+    const float* nz = s.noise;
+    const float* nsd = s.noise_scale;
+    st.run = [=](hipStream_t q) {
+      const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
+      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid), dim3(kBlock), 0, q, stats, f2i, nz, zp, I, T, F, nsd);
+      return PIPER_HIP_OK;
+    };
+    // path expansion counted as the reference's two MatMuls mm(1,F,192,T)
+    st.flops = 2.0 * 2.0 * F * (double)I * T;
+    st.bytes = 2.0 * 4.0 * ((double)F * T + (double)T * I + (double)F * I);
+    s.steps.push_back(st);
+  }
+  s.taps["z_p"] = {zp, (size_t)I * F};
+  // ---------------- flow (reverse)
+  bool flipped = false;
+  const int half = I / 2;
+  for (int f = c.n_flows - 1; f >= 0; f--) {
+    flipped = !flipped;
+    const auto& C = v->flows[f];
+    const std::string p = "flow" + std::to_string(f) + ".";
+    {
+      ConvArgs a = plain(zp, h, I, H, F);
+      a.in_ch_base = flipped ? I - 1 : 0;
+      a.in_ch_sign = flipped ? -1 : 1;
+      add_conv(v, s, p + "pre", C.pre, a, F);
+    }
+    for (int i = 0; i < c.wn_layers; i++) {
+      const bool last = i + 1 == c.wn_layers;
+      ConvArgs a = plain(h, acts, H, H, F);
+      a.padL = (c.wn_kernel - 1) / 2;
+      a.gate = 1;
+      add_conv(v, s, p + "wn" + std::to_string(i) + ".in_gate", C.in[i], a, F);
+      ConvArgs b = plain(acts, h, H, H, F);
+      b.y2 = skip; b.y2_batch_stride = (int64_t)H * F;
+      b.skip = i == 0 ? nullptr : skip;
+      if (last) b.epilogue = EPI_WN_SKIP_LAST;
+      else { b.epilogue = EPI_WN_RES_SKIP; b.wn_c = H; b.res = h; }
+      add_conv(v, s, p + "wn" + std::to_string(i) + ".res_skip", C.rs[i], b, F);
+    }
+    {
+      ConvArgs a = plain(skip, zp, H, I, F);
+      a.epilogue = EPI_RSUB;
+      a.res = zp;
+      a.out_ch_base = flipped ? I - 1 - half : half;
+      a.out_ch_sign = flipped ? -1 : 1;
+      add_conv(v, s, p + "post_sub", C.post, a, F);
+    }
+  }
+  const float* z = zp;
+  if (flipped) {  // odd number of couplings: materialise the last Flip once
+    Step st;
+    st.name = "flow.final_flip";
+    st.run = [=](hipStream_t q) {
+      const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
+      hipLaunchKernelGGL(flip_channels_kernel, dim3(grid), dim3(kBlock), 0, q, zp, zflip, I, F);
+      return PIPER_HIP_OK;
+    };
+    s.steps.push_back(st);
+    z = zflip;
+  }
+  s.taps["z"] = {z, (size_t)I * F};
+  // ---------------- HiFi-GAN generator
+  {
+    ConvArgs a = plain(z, dec0, I, c.up_initial, F);
+    a.padL = 3;
+    add_conv(v, s, "dec.conv_pre", v->conv_pre, a, F);
+  }
+  s.taps["dec_pre"] = {dec0, (size_t)c.up_initial * F};
+  const float* cur[3] = {dec0, nullptr, nullptr};
+  bool cur_is_mrf = false;
+  int L = F;
+  for (int u = 0; u < c.n_ups; u++) {
+    const auto& S = v->stages[u];
+    const int Lo = L * S.stride;  // (L−1)s − 2·pad + K = L·s for the even (K−s) the config check enforces
+    float* up = ar.f32((size_t)S.Cout * Lo);
+    float* r[PIPER_HIP_MAX_RB];
+    float* tmp[PIPER_HIP_MAX_RB];
+    float* tmp2[PIPER_HIP_MAX_RB];
+    float* mid[PIPER_HIP_MAX_RB];
+    for (int j = 0; j < c.n_rb; j++) {
+      r[j] = ar.f32((size_t)S.Cout * Lo);
+      tmp[j] = ar.f32((size_t)S.Cout * Lo);
+      tmp2[j] = c.rb_n_dil > 2 ? ar.f32((size_t)S.Cout * Lo) : nullptr;
+      mid[j] = c.resblock_type == 1 ? ar.f32((size_t)S.Cout * Lo) : nullptr;
+    }
+    if (ar.rc) return ar.rc;
+    const std::string p = "dec.s" + std::to_string(u) + ".";
+    {
+      ConvArgs a;
+      a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
+      a.prologue = cur_is_mrf ? PRO_AVG3_LRELU : PRO_LRELU;
+      a.alpha = 0.1f;
+      a.y = up; a.N = 1; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
+      a.x_batch_stride = (int64_t)S.Cin * L; a.y_batch_stride = (int64_t)S.Cout * Lo; a.y_len = Lo;
+      a.epilogue = EPI_CONVT; a.ct_stride = S.stride; a.ct_padL = S.pad; a.ct_Lout = Lo;
+      a.w = S.up.w; a.bias = S.up.bias; a.Cin = S.up.Cin; a.Cout = S.up.Cout; a.K = S.up.K;
+      Step st;
+      st.name = p + "lrelu_convT";
+      st.run = [ctx, a](hipStream_t q) { return launch_conv_mfma(ctx, q, a); };
+      st.flops = 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
+      st.bytes = 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
+      s.steps.push_back(st);
+    }
+    for (int j = 0; j < c.n_rb; j++) {
+      const int K = c.rb_kernels[j];
+      const float* src = up;
+      for (int di = 0; di < c.rb_n_dil; di++) {
+        const int dil = c.rb_dilations[j][di];
+        const bool lastd = di + 1 == c.rb_n_dil;
+        float* dst = lastd ? r[j] : ((di & 1) ? tmp2[j] : tmp[j]);
+        const std::string nm = p + "rb" + std::to_string(j) + ".c" + std::to_string(di);
+        auto rbconv = [&](const float* in, const float* res, float* out, int dl) {
+          ConvArgs a = plain(in, out, S.Cout, S.Cout, Lo);
+          a.dil = dl; a.padL = (K * dl - dl) / 2; a.prologue = PRO_LRELU; a.alpha = 0.1f; a.res = res;
+          return a;
+        };
+        if (c.resblock_type == 1) {
+          add_conv(v, s, nm + "a_lrelu_conv", S.rb[j][2 * di], rbconv(src, nullptr, mid[j], dil), Lo);
+          add_conv(v, s, nm + "b_lrelu_conv_res", S.rb[j][2 * di + 1], rbconv(mid[j], src, dst, 1), Lo);
+        } else {
+          add_conv(v, s, nm + "_lrelu_conv_res", S.rb[j][di], rbconv(src, src, dst, dil), Lo);
+        }
+        src = dst;
+      }
+    }
+    cur[0] = r[0]; cur[1] = c.n_rb > 1 ? r[1] : nullptr; cur[2] = c.n_rb > 2 ? r[2] : nullptr;
+    cur_is_mrf = true;
+    L = Lo;
+  }
+  if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
+  s.n_samples = L;
+  s.audio = ar.f32((size_t)L);
+  if (ar.rc) return ar.rc;
+  {
+    ConvArgs a;
+    a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
+    a.prologue = PRO_AVG3_LRELU; a.alpha = 0.01f;
+    a.y = s.audio; a.N = 1; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
+    a.epilogue = EPI_TANH;
+    add_conv(v, s, "dec.mrf_lrelu_conv_post_tanh", v->conv_post, a, L);
+  }
+  return PIPER_HIP_OK;
+}
+
+int run_schedule(Slot& s, hipStream_t q) {
+  for (auto& st : s.steps) {
+    int rc = st.run(q);
+    if (rc) return rc;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "schedule launch failed: %s", hipGetErrorString(e));
+  return PIPER_HIP_OK;
+}
+
+int slot_init(piper_hip_voice* v, Slot& s) {
+  if (s.inited) return PIPER_HIP_OK;
+  PH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipEventCreate(&s.ev0), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipEventCreate(&s.ev1), PIPER_HIP_ERR_LAUNCH);
+  s.inited = true;
+  return PIPER_HIP_OK;
+}
+
+int check_utt(const piper_hip_voice* v, const piper_hip_utterance* u, int64_t* F_out) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  if (!u || !u->phoneme_ids || !u->durations) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: null ids/durations");
+  if (u->t < 1) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: need at least one phoneme id");
+  if (u->t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: %d ids exceeds the 4096 cap (PiperCLI.swift:394)", u->t);
+  int64_t F = 0;
+  for (int i = 0; i < u->t; i++) {
+    if (u->durations[i] < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: negative duration");
+    F += u->durations[i];
+  }
+  if (F < 1) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: zero frames");
+  if (F * v->hop > 0x3fffffff / 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: %lld frames too long", (long long)F);
+  *F_out = F;
+  return PIPER_HIP_OK;
+}
+
+}  // namespace
+
+PH_EXPORT int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_config* cfg, const float* blob, int on_device,
+                                     piper_hip_voice** out) {
+  PH_CHECK_CTX(ctx);
+  if (!out || !blob) PH_FAIL(PIPER_HIP_ERR_ARG, "voice_create: null argument");
+  *out = nullptr;
+  int rc = validate_config(cfg);
+  if (rc) return rc;
+  if (cfg->hidden % 32 || cfg->inter % 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "voice: hidden must be a multiple of 32 and inter of 64");
+  PH_HIP(hipSetDevice(ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  std::unique_ptr<piper_hip_voice> v(new piper_hip_voice());
+  v->ctx = ctx;
+  v->cfg = *cfg;
+  v->hop = 1;
+  for (int u = 0; u < cfg->n_ups; u++) v->hop *= cfg->up_rates[u];
+  IndexOut io{&v->index};
+  v->blob_floats = piper_hip_layout_walk(cfg, index_visit, &io);
+  void* p = nullptr;
+  if ((rc = ctx->pool.alloc(v->blob_floats * sizeof(float), &p))) return rc;
+  v->blob = (float*)p;
+  v->owned.push_back(p);
+  hipStream_t s = ctx->default_stream;
+  PH_HIP(hipMemcpyAsync(v->blob, blob, v->blob_floats * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s),
+         PIPER_HIP_ERR_LAUNCH);
+  // measure, allocate, pack
+  auto fail = [&](int code) {
+    for (void* q : v->owned) (void)ctx->pool.release(q);
+    return code;
+  };
+  Packer dry{v.get(), 0, s};
+  compile_weights(v.get(), dry, true, nullptr);
+  v->packed_floats = dry.off;
+  if ((rc = ctx->pool.alloc(v->packed_floats * sizeof(float), &p))) return fail(rc);
+  v->packed = (float*)p;
+  v->owned.push_back(p);
+  std::vector<float*> qkvb;
+  for (int l = 0; l < cfg->n_layers; l++) {
+    if ((rc = ctx->pool.alloc((size_t)3 * cfg->hidden * sizeof(float), &p))) return fail(rc);
+    v->owned.push_back(p);
+    qkvb.push_back((float*)p);
+  }
+  Packer pk{v.get(), 0, s};
+  if ((rc = compile_weights(v.get(), pk, false, &qkvb))) return fail(rc);
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    fail(0);
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_create: packing failed: %s", hipGetErrorString(e));
+  }
+  *out = v.release();
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& s : v->slots) slot_release(v, s, true);
+  for (void* p : v->owned) (void)v->ctx->pool.release(p);
+  delete v;
+}
+
+PH_EXPORT int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_utterance* u) {
+  int64_t F = 0;
+  if (check_utt(v, u, &F)) return -1;
+  return F * v->hop;
+}
+
+PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot) {
+  int64_t F64 = 0;
+  int rc = check_utt(v, u, &F64);
+  if (rc) return rc;
+  if (slot < 0 || slot >= kMaxSlots) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d out of range [0,%d)", slot, kMaxSlots);
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  Slot& s = v->slots[slot];
+  if ((rc = slot_init(v, s))) return rc;
+  const int T = u->t, F = (int)F64;
+  // the previous launch on this slot may still be reading the inputs
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  const bool rebuild = (s.T != T || s.F != F || !s.exec);
+  if (rebuild) {
+    if ((rc = build_schedule(v, s, T, F))) { slot_release(v, s, false); return rc; }
+  }
+  if (s.h_cap_t < (size_t)T) {
+    if (s.h_ids) (void)hipHostFree(s.h_ids);
+    PH_HIP(hipHostMalloc((void**)&s.h_ids, (size_t)T * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
+    s.h_cap_t = T;
+  }
+  if (s.h_cap_f < (size_t)F) {
+    if (s.h_f2i) (void)hipHostFree(s.h_f2i);
+    PH_HIP(hipHostMalloc((void**)&s.h_f2i, (size_t)F * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
+    s.h_cap_f = F;
+  }
+  memcpy(s.h_ids, u->phoneme_ids, (size_t)T * sizeof(int64_t));
+  {
+    int f = 0;  // generate_path: frame f belongs to the phoneme whose cumulative duration covers it
+    for (int t = 0; t < T; t++)
+      for (int j = 0; j < u->durations[t]; j++) s.h_f2i[f++] = t;
+  }
+  s.h_noise_scale = u->noise_scale;
+  PH_HIP(hipMemcpyAsync(s.noise_scale, &s.h_noise_scale, sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  if (u->noise)
+    PH_HIP(hipMemcpyAsync(s.noise, u->noise, (size_t)v->cfg.inter * F * sizeof(float), hipMemcpyHostToDevice, s.stream),
+           PIPER_HIP_ERR_LAUNCH);
+  else
+    PH_HIP(hipMemsetAsync(s.noise, 0, (size_t)v->cfg.inter * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // u->noise is caller memory
+  if (rebuild) {
+    // one eager pass validates every launch (and sets kernel attributes) before capture
+    if ((rc = run_schedule(s, s.stream))) { slot_release(v, s, false); return rc; }
+    hipError_t e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) {
+      slot_release(v, s, false);
+      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
+    }
+    PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
+    rc = run_schedule(s, s.stream);
+    hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
+    if (rc || ce != hipSuccess) {
+      slot_release(v, s, false);
+      if (rc) return rc;
+      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph capture failed: %s", hipGetErrorString(ce));
+    }
+    ce = hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0);
+    if (ce != hipSuccess) {
+      slot_release(v, s, false);
+      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph instantiate failed: %s", hipGetErrorString(ce));
+    }
+  }
+  s.timed = false;
+  return slot;
+}
+
+PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot& s = v->slots[slot];
+  PH_HIP(hipEventRecord(s.ev0, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipGraphLaunch(s.exec, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipEventRecord(s.ev1, s.stream), PIPER_HIP_ERR_LAUNCH);
+  s.timed = true;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot& s = v->slots[slot];
+  if (host_audio) {
+    if (max_samples < s.n_samples) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)s.n_samples);
+    PH_HIP(hipMemcpyAsync(host_audio, s.audio, (size_t)s.n_samples * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
+  }
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u, float* host_audio,
+                                         int64_t max_samples, int64_t* n_samples) {
+  int rc = piper_hip_voice_prepare(v, u, 0);
+  if (rc < 0) return rc;
+  if ((rc = piper_hip_voice_launch(v, 0))) return rc;
+  if ((rc = piper_hip_voice_collect(v, 0, host_audio, max_samples))) return rc;
+  if (n_samples) *n_samples = v->slots[0].n_samples;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name, float* host, size_t max_floats,
+                                  size_t* n_floats) {
+  if (!v || !name) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot& s = v->slots[slot];
+  auto it = s.taps.find(name);
+  if (it == s.taps.end()) PH_FAIL(PIPER_HIP_ERR_ARG, "unknown tap '%s'", name);
+  if (n_floats) *n_floats = it->second.second;
+  if (host) {
+    if (max_floats < it->second.second) PH_FAIL(PIPER_HIP_ERR_SHAPE, "tap buffer too small");
+    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(hipMemcpy(host, it->second.first, it->second.second * sizeof(float), hipMemcpyDeviceToHost), PIPER_HIP_ERR_LAUNCH);
+  }
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_last_gpu_ms(piper_hip_voice* v, int slot, double* ms) {
+  if (!v || !ms) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].timed) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no timed launch", slot);
+  Slot& s = v->slots[slot];
+  PH_HIP(hipEventSynchronize(s.ev1), PIPER_HIP_ERR_LAUNCH);
+  float f = 0;
+  PH_HIP(hipEventElapsedTime(&f, s.ev0, s.ev1), PIPER_HIP_ERR_LAUNCH);
+  *ms = f;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT piper_hip_stream piper_hip_voice_slot_stream(piper_hip_voice* v, int slot) {
+  if (!v || slot < 0 || slot >= kMaxSlots) return nullptr;
+  return (piper_hip_stream)v->slots[slot].stream;
+}
+
+PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, piper_hip_kernel_stat* out, int max_entries,
+                                      int* n_entries) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  if (iters < 1) iters = 1;
+  Slot& s = v->slots[slot];
+  const int n = (int)s.steps.size();
+  if (n_entries) *n_entries = n;
+  if (!out) return PIPER_HIP_OK;
+  std::vector<hipEvent_t> ev((size_t)n + 1);
+  for (auto& e : ev) PH_HIP(hipEventCreate(&e), PIPER_HIP_ERR_LAUNCH);
+  std::vector<double> acc((size_t)n, 0.0);
+  int rc = PIPER_HIP_OK;
+  for (int it = 0; it < iters + 1 && !rc; it++) {  // first pass is warm-up
+    PH_HIP(hipEventRecord(ev[0], s.stream), PIPER_HIP_ERR_LAUNCH);
+    for (int i = 0; i < n && !rc; i++) {
+      rc = s.steps[i].run(s.stream);
+      if (!rc && hipEventRecord(ev[i + 1], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
+    }
+    if (rc) break;
+    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    if (it == 0) continue;
+    for (int i = 0; i < n; i++) {
+      float ms = 0;
+      PH_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), PIPER_HIP_ERR_LAUNCH);
+      acc[i] += ms * 1000.0;
+    }
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  for (int i = 0; i < n && i < max_entries; i++) {
+    memset(&out[i], 0, sizeof out[i]);
+    snprintf(out[i].name, sizeof out[i].name, "%s", s.steps[i].name.c_str());
+    out[i].avg_us = acc[i] / iters;
+    out[i].flops = s.steps[i].flops;
+    out[i].bytes = s.steps[i].bytes;
+  }
+  return PIPER_HIP_OK;
+}

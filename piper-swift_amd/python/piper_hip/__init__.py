@@ -1,0 +1,543 @@
+"""ctypes shim over lib/libpiper_hip.so (include/piper_hip.h).
+
+Host-side mirror of the reference's operator interface for this path: `HipBackend` exposes the
+`MetalBackend` per-op methods (Sources/PiperMetal/Execution/MetalBackend.swift) with the same names
+and argument meaning — buffer + shape in, (buffer, shape) out, optional stream standing in for
+`commandBuffer:` — and raises `ExecutionError` subclasses where the Swift code `throws`.
+
+There is NO CPU fallback here: if the shared library is missing, or no gfx950 device is present,
+construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libpiper_hip.so"))
+
+# ---- errors: ExecutionError (CPUBackend.swift:3-17) ----
+
+
+class ExecutionError(RuntimeError):
+    code = None
+
+
+class ShapeMismatch(ExecutionError):
+    code = -1
+
+
+class TypeMismatch(ExecutionError):
+    code = -2
+
+
+class UnsupportedOp(ExecutionError):
+    code = -3
+
+
+class DeviceUnavailable(ExecutionError):  # ExecutionError.metalUnavailable
+    code = -4
+
+
+class AllocationFailed(ExecutionError):
+    code = -5
+
+
+class LaunchFailed(ExecutionError):
+    code = -6
+
+
+class InvalidArgument(ExecutionError):
+    code = -7
+
+
+_ERRORS = {c.code: c for c in (ShapeMismatch, TypeMismatch, UnsupportedOp, DeviceUnavailable, AllocationFailed,
+                               LaunchFailed, InvalidArgument)}
+
+RELU, LEAKYRELU, TANH, SIGMOID, EXP, NEG, SQRT, SOFTPLUS, CEIL, ERF = range(10)
+ADD, SUB, MUL, DIV, POW = range(5)
+
+c_f32p = C.POINTER(C.c_float)
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_vp = C.c_void_p
+
+
+class Conv1dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("stride", "dilation", "pad_l", "pad_r", "groups")]
+
+
+class ConvTranspose1dParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("stride", "dilation", "pad_l", "pad_r", "output_padding", "groups")]
+
+
+class VoiceConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_vocab", "hidden", "n_heads", "n_layers", "ffn", "ffn_kernel", "window",
+                                         "inter", "n_flows", "wn_layers", "wn_kernel", "up_initial", "n_ups")] + [
+        ("up_rates", C.c_int32 * 4), ("up_kernels", C.c_int32 * 4), ("resblock_type", C.c_int32), ("n_rb", C.c_int32),
+        ("rb_kernels", C.c_int32 * 3), ("rb_n_dil", C.c_int32), ("rb_dilations", (C.c_int32 * 3) * 3),
+        ("sample_rate", C.c_int32)]
+
+    @property
+    def hop(self):
+        h = 1
+        for i in range(self.n_ups):
+            h *= self.up_rates[i]
+        return h
+
+
+class TensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("kind", C.c_int32), ("rank", C.c_int32), ("shape", C.c_int64 * 3),
+                ("fan_in", C.c_int64), ("offset", C.c_uint64), ("count", C.c_uint64)]
+
+
+class Utterance(C.Structure):
+    _fields_ = [("phoneme_ids", c_i64p), ("t", C.c_int32), ("durations", c_i32p), ("noise", c_f32p),
+                ("noise_scale", C.c_float)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("avg_us", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+# every symbol include/piper_hip.h declares: (restype, argtypes)
+_PROTOS = {
+    "piper_hip_last_error": (C.c_char_p, []),
+    "piper_hip_abi_version": (C.c_int, []),
+    "piper_hip_device_count": (C.c_int, []),
+    "piper_hip_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
+    "piper_hip_destroy": (None, [c_vp]),
+    "piper_hip_alloc": (C.c_int, [c_vp, C.c_size_t, C.POINTER(c_vp)]),
+    "piper_hip_free": (C.c_int, [c_vp, c_vp]),
+    "piper_hip_upload_f32": (C.c_int, [c_vp, c_f32p, C.c_size_t, C.POINTER(c_vp)]),
+    "piper_hip_upload_i64": (C.c_int, [c_vp, c_i64p, C.c_size_t, C.POINTER(c_vp)]),
+    "piper_hip_download_f32": (C.c_int, [c_vp, c_vp, c_f32p, C.c_size_t]),
+    "piper_hip_stream_create": (C.c_int, [c_vp, C.POINTER(c_vp)]),
+    "piper_hip_stream_destroy": (C.c_int, [c_vp, c_vp]),
+    "piper_hip_stream_sync": (C.c_int, [c_vp, c_vp]),
+    "piper_hip_timer_begin": (C.c_int, [c_vp, c_vp]),
+    "piper_hip_timer_end": (C.c_int, [c_vp, c_vp, C.POINTER(C.c_double)]),
+    "piper_hip_conv1d_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, c_vp, C.POINTER(Conv1dParams),
+                                       C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_convtranspose1d_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, c_vp,
+                                                C.POINTER(ConvTranspose1dParams), C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_matmul_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_softmax_lastdim_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
+    "piper_hip_unary_f32": (C.c_int, [c_vp, C.c_int, c_vp, C.c_size_t, C.c_float, C.POINTER(c_vp), c_vp]),
+    "piper_hip_binary_broadcast_f32": (C.c_int, [c_vp, C.c_int, c_vp, c_i64p, C.c_int, c_vp, c_i64p, C.c_int,
+                                                 C.POINTER(c_vp), c_i64p, C.POINTER(C.c_int), c_vp]),
+    "piper_hip_pad_constant_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, c_i64p, C.c_float, C.POINTER(c_vp), c_i64p,
+                                             c_vp]),
+    "piper_hip_slice_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                      C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_transpose_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, c_i32p, C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_concat2_axis1_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_split2_axis1_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int64, C.POINTER(c_vp), C.POINTER(c_vp), c_vp]),
+    "piper_hip_expand_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
+    "piper_hip_reduce_mean_lastdim_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
+    "piper_hip_rel_attention_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64,
+                                              C.c_int64, C.c_int64, C.POINTER(c_vp), c_vp]),
+    "piper_hip_add_layernorm_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                              C.POINTER(c_vp), c_vp]),
+    "piper_hip_wavenet_layer_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64,
+                                              C.c_int64, C.c_int64, C.c_int, C.POINTER(c_vp), C.POINTER(c_vp), c_vp]),
+    "piper_hip_hifigan_resblock_f32": (C.c_int, [c_vp, C.c_int, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_i32p,
+                                                 C.c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.c_float, C.POINTER(c_vp),
+                                                 c_vp]),
+    "piper_hip_voice_config_preset": (C.c_int, [C.c_int, C.POINTER(VoiceConfig)]),
+    "piper_hip_voice_blob_floats": (C.c_int, [C.POINTER(VoiceConfig), C.POINTER(C.c_size_t)]),
+    "piper_hip_voice_blob_layout": (C.c_int, [C.POINTER(VoiceConfig), C.POINTER(TensorInfo), C.c_int,
+                                              C.POINTER(C.c_int)]),
+    "piper_hip_voice_synthetic_blob": (C.c_int, [C.POINTER(VoiceConfig), C.c_uint64, c_f32p, C.c_size_t]),
+    "piper_hip_voice_create": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_vp, C.c_int, C.POINTER(c_vp)]),
+    "piper_hip_voice_destroy": (None, [c_vp]),
+    "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
+    "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
+    "piper_hip_voice_launch": (C.c_int, [c_vp, C.c_int]),
+    "piper_hip_voice_collect": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64]),
+    "piper_hip_voice_synthesize": (C.c_int, [c_vp, C.POINTER(Utterance), c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    "piper_hip_voice_tap": (C.c_int, [c_vp, C.c_int, C.c_char_p, c_f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "piper_hip_voice_last_gpu_ms": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double)]),
+    "piper_hip_voice_slot_stream": (c_vp, [c_vp, C.c_int]),
+    "piper_hip_voice_profile": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and bind every declared symbol (raises if one is missing)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise DeviceUnavailable(f"{p} not found: build it with `make -C piper-swift_amd` "
+                                "(python __graft_entry__.py build). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().piper_hip_last_error().decode("utf-8", "replace")
+        raise _ERRORS.get(rc, ExecutionError)(msg or f"piper_hip error {rc}")
+
+
+def _i64(a):
+    arr = (C.c_int64 * len(a))(*[int(v) for v in a])
+    return arr
+
+
+def device_count():
+    return load_library().piper_hip_device_count()
+
+
+class DeviceBuffer:
+    """An MTLBuffer stand-in: device pointer + element count, owned by a backend's pool."""
+
+    def __init__(self, backend, ptr, count, owned=True):
+        self.backend, self.ptr, self.count, self.owned = backend, ptr, int(count), owned
+
+    def free(self):
+        if self.owned and self.ptr:
+            _check(self.backend.lib.piper_hip_free(self.backend.ctx, self.ptr))
+        self.ptr = None
+
+
+def _ptr(b):
+    if b is None:
+        return None
+    return b.ptr if isinstance(b, DeviceBuffer) else b
+
+
+class HipBackend:
+    """MetalBackend's hot-path surface (MetalBackend.swift:8-3427) over the C-ABI."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        ctx = c_vp()
+        _check(self.lib.piper_hip_create(device, C.byref(ctx)))
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            self.lib.piper_hip_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- buffers (MetalBackend.swift:34-39, 963-993)
+    def allocateBuffer(self, length):
+        p = c_vp()
+        _check(self.lib.piper_hip_alloc(self.ctx, length, C.byref(p)))
+        return DeviceBuffer(self, p.value, length // 4)
+
+    def uploadFloat32(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        p = c_vp()
+        _check(self.lib.piper_hip_upload_f32(self.ctx, a.ctypes.data_as(c_f32p), a.size, C.byref(p)))
+        return DeviceBuffer(self, p.value, a.size)
+
+    def downloadFloat32(self, buf, count=None):
+        n = buf.count if count is None else int(count)
+        out = np.empty(n, np.float32)
+        _check(self.lib.piper_hip_download_f32(self.ctx, _ptr(buf), out.ctypes.data_as(c_f32p), n))
+        return out
+
+    def makeCommandBuffer(self):
+        s = c_vp()
+        _check(self.lib.piper_hip_stream_create(self.ctx, C.byref(s)))
+        return s
+
+    def flush(self, stream):
+        _check(self.lib.piper_hip_stream_sync(self.ctx, stream))
+
+    def _out(self, p, shape):
+        return DeviceBuffer(self, p.value, int(np.prod(shape)) if len(shape) else 1), [int(s) for s in shape]
+
+    # -- ops
+    def conv1dF32(self, input, inputShape, weight, weightShape, bias, stride=1, dilation=1, padL=0, padR=0, groups=1,
+                  commandBuffer=None):
+        if len(inputShape) != 3:
+            raise ShapeMismatch("conv1dF32 input must be [N,C,L]")
+        if len(weightShape) != 3:
+            raise ShapeMismatch("conv1dF32 weight must be [C_out,C_in,K]")
+        prm = Conv1dParams(stride, dilation, padL, padR, groups)
+        p, osh = c_vp(), (C.c_int64 * 3)()
+        _check(self.lib.piper_hip_conv1d_f32(self.ctx, _ptr(input), _i64(inputShape), _ptr(weight), _i64(weightShape),
+                                             _ptr(bias), C.byref(prm), C.byref(p), osh, commandBuffer))
+        return self._out(p, list(osh))
+
+    def convTranspose1dF32(self, input, inputShape, weight, weightShape, bias, stride=1, dilation=1, padL=0, padR=0,
+                           outputPadding=0, groups=1, commandBuffer=None):
+        if len(inputShape) != 3:
+            raise ShapeMismatch("convTranspose1dF32 input must be [N,C,L]")
+        if len(weightShape) != 3:
+            raise ShapeMismatch("convTranspose1dF32 weight must be [C_in,C_out_per_group,K]")
+        prm = ConvTranspose1dParams(stride, dilation, padL, padR, outputPadding, groups)
+        p, osh = c_vp(), (C.c_int64 * 3)()
+        _check(self.lib.piper_hip_convtranspose1d_f32(self.ctx, _ptr(input), _i64(inputShape), _ptr(weight),
+                                                      _i64(weightShape), _ptr(bias), C.byref(prm), C.byref(p), osh,
+                                                      commandBuffer))
+        return self._out(p, list(osh))
+
+    def matmulF32(self, a, aShape, b, bShape, commandBuffer=None):
+        if len(aShape) < 2 or len(bShape) < 2:
+            raise ShapeMismatch(f"matmulF32 requires rank>=2 (got {aShape} x {bShape})")
+        if len(aShape) != len(bShape):
+            raise ShapeMismatch(f"matmulF32 rank mismatch (got {len(aShape)} vs {len(bShape)})")
+        r = len(aShape)
+        p, osh = c_vp(), (C.c_int64 * r)()
+        _check(self.lib.piper_hip_matmul_f32(self.ctx, _ptr(a), _i64(aShape), _ptr(b), _i64(bShape), r, C.byref(p), osh,
+                                             commandBuffer))
+        return self._out(p, list(osh))
+
+    def softmaxLastDimF32(self, input, shape, commandBuffer=None):
+        if len(shape) < 1:
+            raise ShapeMismatch("softmaxLastDimF32 requires non-empty last dim")
+        p = c_vp()
+        _check(self.lib.piper_hip_softmax_lastdim_f32(self.ctx, _ptr(input), _i64(shape), len(shape), C.byref(p),
+                                                      commandBuffer))
+        return self._out(p, shape)
+
+    def unaryF32(self, op, input, count, alpha=0.0, commandBuffer=None):
+        p = c_vp()
+        _check(self.lib.piper_hip_unary_f32(self.ctx, op, _ptr(input), count, alpha, C.byref(p), commandBuffer))
+        return DeviceBuffer(self, p.value, count)
+
+    def reluF32(self, input, count, commandBuffer=None):
+        return self.unaryF32(RELU, input, count, 0.0, commandBuffer)
+
+    def leakyReluF32(self, input, count, alpha=0.01, commandBuffer=None):
+        return self.unaryF32(LEAKYRELU, input, count, alpha, commandBuffer)
+
+    def tanhF32(self, input, count, commandBuffer=None):
+        return self.unaryF32(TANH, input, count, 0.0, commandBuffer)
+
+    def sigmoidF32(self, input, count, commandBuffer=None):
+        return self.unaryF32(SIGMOID, input, count, 0.0, commandBuffer)
+
+    def binaryBroadcastF32(self, op, a, aShape, b, bShape, commandBuffer=None):
+        r = max(len(aShape), len(bShape))
+        p, osh, orank = c_vp(), (C.c_int64 * max(r, 1))(), C.c_int()
+        _check(self.lib.piper_hip_binary_broadcast_f32(self.ctx, op, _ptr(a), _i64(aShape), len(aShape), _ptr(b),
+                                                       _i64(bShape), len(bShape), C.byref(p), osh, C.byref(orank),
+                                                       commandBuffer))
+        return self._out(p, list(osh)[:orank.value])
+
+    def addF32(self, a, aShape, b, bShape, commandBuffer=None):
+        return self.binaryBroadcastF32(ADD, a, aShape, b, bShape, commandBuffer)
+
+    def subF32(self, a, aShape, b, bShape, commandBuffer=None):
+        return self.binaryBroadcastF32(SUB, a, aShape, b, bShape, commandBuffer)
+
+    def mulF32(self, a, aShape, b, bShape, commandBuffer=None):
+        return self.binaryBroadcastF32(MUL, a, aShape, b, bShape, commandBuffer)
+
+    def divF32(self, a, aShape, b, bShape, commandBuffer=None):
+        return self.binaryBroadcastF32(DIV, a, aShape, b, bShape, commandBuffer)
+
+    def padConstantF32(self, input, shape, pads, value=0.0, commandBuffer=None):
+        r = len(shape)
+        p, osh = c_vp(), (C.c_int64 * r)()
+        _check(self.lib.piper_hip_pad_constant_f32(self.ctx, _ptr(input), _i64(shape), r, _i64(pads), value, C.byref(p),
+                                                   osh, commandBuffer))
+        return self._out(p, list(osh))
+
+    def sliceF32(self, input, shape, axis, start, end, step=1, commandBuffer=None):
+        r = len(shape)
+        p, osh = c_vp(), (C.c_int64 * r)()
+        _check(self.lib.piper_hip_slice_f32(self.ctx, _ptr(input), _i64(shape), r, axis, start, end, step, C.byref(p), osh,
+                                            commandBuffer))
+        return self._out(p, list(osh))
+
+    def transposeF32(self, input, shape, perm, commandBuffer=None):
+        r = len(shape)
+        if len(perm) != r:
+            raise ShapeMismatch(f"Transpose perm rank mismatch: perm={perm} shape={shape}")
+        p, osh = c_vp(), (C.c_int64 * r)()
+        pm = (C.c_int32 * r)(*perm)
+        _check(self.lib.piper_hip_transpose_f32(self.ctx, _ptr(input), _i64(shape), r, pm, C.byref(p), osh, commandBuffer))
+        return self._out(p, list(osh))
+
+    def concat2Axis1F32(self, a, aShape, b, bShape, commandBuffer=None):
+        p, osh = c_vp(), (C.c_int64 * 3)()
+        _check(self.lib.piper_hip_concat2_axis1_f32(self.ctx, _ptr(a), _i64(aShape), _ptr(b), _i64(bShape), C.byref(p),
+                                                    osh, commandBuffer))
+        return self._out(p, list(osh))
+
+    def split2Axis1F32(self, input, shape, c0, commandBuffer=None):
+        p0, p1 = c_vp(), c_vp()
+        _check(self.lib.piper_hip_split2_axis1_f32(self.ctx, _ptr(input), _i64(shape), c0, C.byref(p0), C.byref(p1),
+                                                   commandBuffer))
+        n, c, l = shape
+        return self._out(p0, [n, c0, l]), self._out(p1, [n, c - c0, l])
+
+    def expandF32(self, input, inShape, outShape, commandBuffer=None):
+        p = c_vp()
+        _check(self.lib.piper_hip_expand_f32(self.ctx, _ptr(input), _i64(inShape), _i64(outShape), len(outShape),
+                                             C.byref(p), commandBuffer))
+        return self._out(p, outShape)[0]
+
+    def reduceMeanLastDimF32(self, input, shape, commandBuffer=None):
+        p = c_vp()
+        _check(self.lib.piper_hip_reduce_mean_lastdim_f32(self.ctx, _ptr(input), _i64(shape), len(shape), C.byref(p),
+                                                          commandBuffer))
+        return self._out(p, list(shape[:-1]))
+
+    # -- fused
+    def relAttentionF32(self, q, k, v, embRelK, embRelV, n, heads, headDim, t, window, commandBuffer=None):
+        p = c_vp()
+        _check(self.lib.piper_hip_rel_attention_f32(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(embRelK), _ptr(embRelV), n,
+                                                    heads, headDim, t, window, C.byref(p), commandBuffer))
+        return self._out(p, [n, heads * headDim, t])
+
+    def addLayerNormF32(self, x, y, gamma, beta, n, c, t, eps=1e-5, commandBuffer=None):
+        p = c_vp()
+        _check(self.lib.piper_hip_add_layernorm_f32(self.ctx, _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), n, c, t, eps,
+                                                    C.byref(p), commandBuffer))
+        return self._out(p, [n, c, t])
+
+    def wavenetLayerF32(self, x, skipIn, wIn, bIn, wRs, bRs, n, c, t, k, dilation, last, commandBuffer=None):
+        px, ps = c_vp(), c_vp()
+        _check(self.lib.piper_hip_wavenet_layer_f32(self.ctx, _ptr(x), _ptr(skipIn), _ptr(wIn), _ptr(bIn), _ptr(wRs),
+                                                    _ptr(bRs), n, c, t, k, dilation, int(bool(last)), C.byref(px),
+                                                    C.byref(ps), commandBuffer))
+        xo = None if last else self._out(px, [n, c, t])[0]
+        return xo, self._out(ps, [n, c, t])[0]
+
+    def hifiganResblockF32(self, type, x, n, c, t, k, dilations, weights, biases, slope=0.1, commandBuffer=None):
+        nd = len(dilations)
+        d = (C.c_int32 * nd)(*dilations)
+        w = (c_vp * len(weights))(*[_ptr(b) for b in weights])
+        b = (c_vp * len(biases))(*[_ptr(x_) for x_ in biases])
+        p = c_vp()
+        _check(self.lib.piper_hip_hifigan_resblock_f32(self.ctx, type, _ptr(x), n, c, t, k, d, nd, w, b, slope, C.byref(p),
+                                                       commandBuffer))
+        return self._out(p, [n, c, t])[0]
+
+
+# ---------------------------------------------------------------- voice level (PiperMetalRuntime)
+
+def voice_config(quality="medium"):
+    cfg = VoiceConfig()
+    _check(load_library().piper_hip_voice_config_preset({"medium": 0, "high": 1}[quality], C.byref(cfg)))
+    return cfg
+
+
+def blob_floats(cfg):
+    n = C.c_size_t()
+    _check(load_library().piper_hip_voice_blob_floats(C.byref(cfg), C.byref(n)))
+    return n.value
+
+
+def blob_layout(cfg):
+    lib = load_library()
+    n = C.c_int()
+    _check(lib.piper_hip_voice_blob_layout(C.byref(cfg), None, 0, C.byref(n)))
+    arr = (TensorInfo * n.value)()
+    _check(lib.piper_hip_voice_blob_layout(C.byref(cfg), arr, n.value, C.byref(n)))
+    return [dict(name=t.name.decode(), kind=t.kind, shape=[int(t.shape[i]) for i in range(t.rank)], fan_in=int(t.fan_in),
+                 offset=int(t.offset), count=int(t.count)) for t in arr]
+
+
+def synthetic_blob(cfg, seed=1234):
+    """Host-only (no GPU): the synthetic voice of SURVEY.md §8d."""
+    n = blob_floats(cfg)
+    blob = np.empty(n, np.float32)
+    _check(load_library().piper_hip_voice_synthetic_blob(C.byref(cfg), seed, blob.ctypes.data_as(c_f32p), n))
+    return blob
+
+
+class HipRuntime:
+    """PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80) over the C-ABI, durations/noise injected."""
+
+    def __init__(self, backend, cfg, blob, on_device=False):
+        self.backend, self.cfg, self.lib = backend, cfg, backend.lib
+        v = c_vp()
+        if on_device:
+            ptr = blob
+        else:
+            self._blob = np.ascontiguousarray(blob, np.float32)
+            ptr = self._blob.ctypes.data_as(c_vp)
+        _check(self.lib.piper_hip_voice_create(backend.ctx, C.byref(cfg), ptr, int(on_device), C.byref(v)))
+        self.voice = v
+        self._keep = {}
+
+    def close(self):
+        if self.voice:
+            self.lib.piper_hip_voice_destroy(self.voice)
+            self.voice = None
+
+    def _utt(self, ids, durations, noise, noise_scale):
+        ids = np.ascontiguousarray(ids, np.int64)
+        dur = np.ascontiguousarray(durations, np.int32)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+        u = Utterance(ids.ctypes.data_as(c_i64p), len(ids), dur.ctypes.data_as(c_i32p),
+                      None if nz is None else nz.ctypes.data_as(c_f32p), float(noise_scale))
+        return u, (ids, dur, nz)
+
+    def num_samples(self, ids, durations):
+        u, _k = self._utt(ids, durations, None, 0.0)
+        return int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u)))
+
+    def synthesize(self, phonemeIDs, durations, noise=None, noiseScale=0.667):
+        u, _k = self._utt(phonemeIDs, durations, noise, noiseScale)
+        n = int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u)))
+        out = np.empty(max(n, 1), np.float32)
+        got = C.c_int64()
+        _check(self.lib.piper_hip_voice_synthesize(self.voice, C.byref(u), out.ctypes.data_as(c_f32p), n, C.byref(got)))
+        return out[:got.value]
+
+    def prepare(self, slot, phonemeIDs, durations, noise=None, noiseScale=0.667):
+        u, k = self._utt(phonemeIDs, durations, noise, noiseScale)
+        self._keep[slot] = (k, int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u))))
+        rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def launch(self, slot):
+        _check(self.lib.piper_hip_voice_launch(self.voice, slot))
+
+    def collect(self, slot, want_audio=True):
+        n = self._keep[slot][1]
+        if not want_audio:
+            _check(self.lib.piper_hip_voice_collect(self.voice, slot, None, 0))
+            return None
+        out = np.empty(max(n, 1), np.float32)
+        _check(self.lib.piper_hip_voice_collect(self.voice, slot, out.ctypes.data_as(c_f32p), n))
+        return out[:n]
+
+    def tap(self, slot, name, max_floats):
+        out = np.empty(max_floats, np.float32)
+        n = C.c_size_t()
+        _check(self.lib.piper_hip_voice_tap(self.voice, slot, name.encode(), out.ctypes.data_as(c_f32p), max_floats,
+                                            C.byref(n)))
+        return out[:n.value]
+
+    def last_gpu_ms(self, slot):
+        ms = C.c_double()
+        _check(self.lib.piper_hip_voice_last_gpu_ms(self.voice, slot, C.byref(ms)))
+        return ms.value
+
+    def profile(self, slot, iters=5, max_entries=512):
+        arr = (KernelStat * max_entries)()
+        n = C.c_int()
+        _check(self.lib.piper_hip_voice_profile(self.voice, slot, iters, arr, max_entries, C.byref(n)))
+        return [dict(name=a.name.decode(), avg_us=a.avg_us, flops=a.flops, bytes=a.bytes) for a in arr[:n.value]]
