@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's scale bench (PiperCLI.swift:381-551 `--scale-bench`; ORT twin bench/benchmark_onnxruntime.py)
+on the MI355X-native path.
+
+A "step" is one utterance through the whole hot path (text encoder → flow → HiFi-GAN), inputs (ids, durations, noise)
+already resident in HBM when the timed region starts, waveform copied back to the host inside the step.
+N = 1 workload: BASELINE.json configs[1] — en_GB medium geometry, factor 8 (112 ids, 336 frames, 86 016 samples, 3.901 s
+of 22 050 Hz audio), fp32, synthetic weights (seed 1234), durations pinned to 3 frames/id, injected noise.
+N > 1: one process per GPU (torchrun), weights broadcast ONCE over RCCL/xGMI from rank 0, then each rank synthesises its
+own utterances with no data-path collective (weak scaling).
+
+Prints ONE JSON line (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "piper-swift_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FIXTURE_IDS = [1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2]  # bench/fixtures/test_summary.json:8
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def utterance(factor, seed, inter=192):
+    import katdata as kd
+    ids = (FIXTURE_IDS * factor)[:4096]  # PiperCLI.swift:467-473
+    dur = [3] * len(ids)
+    noise = kd.sym(seed, (inter, 3 * len(ids)), 1.7320508)  # unit-variance, seeded
+    return ids, dur, noise
+
+
+def percentile(xs, p):  # PiperCLI.swift:425-436
+    s = sorted(xs)
+    k = (len(s) - 1) * (p / 100.0)
+    f, c = int(np.floor(k)), int(np.ceil(k))
+    return s[f] if f == c else s[f] + (s[c] - s[f]) * (k - f)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--factor", type=int, default=8)
+    ap.add_argument("--quality", default="medium", choices=["medium", "high"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-bench", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--slots", type=int, default=8, help="utterances in flight for the batch-throughput side metric")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import piper_hip as ph
+    cfg = ph.voice_config(args.quality)
+    n_floats = ph.blob_floats(cfg)
+    bcast_ms = None
+    keep = []
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one-shot weight broadcast over RCCL/xGMI: rank 0 owns the blob, everyone else receives it in HBM
+        wbuf = torch.empty(n_floats, dtype=torch.float32, device="cuda")
+        if rank == 0:
+            wbuf.copy_(torch.from_numpy(ph.synthetic_blob(cfg, 1234)))
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(wbuf, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        backend = ph.HipBackend(local_rank)
+        rt = ph.HipRuntime(backend, cfg, wbuf.data_ptr(), on_device=True)
+        keep.append(wbuf)
+    else:
+        backend = ph.HipBackend(0)
+        rt = ph.HipRuntime(backend, cfg, ph.synthetic_blob(cfg, 1234))
+
+    def barrier():
+        if distributed:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    hop, sr = cfg.hop, cfg.sample_rate
+    ids, dur, noise = utterance(args.factor, 1234 + rank, cfg.inter)
+    n_samples = rt.num_samples(ids, dur)
+    audio_sec = n_samples / sr
+    rt.prepare(0, ids, dur, noise, 0.667)
+
+    def step():
+        rt.launch(0)
+        return rt.collect(0)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    gpu_ms = []
+    for _ in range(args.steps):
+        step()
+        gpu_ms.append(rt.last_gpu_ms(0))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        import torch
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * args.steps * audio_sec / elapsed  # whole-job audio-seconds per wall-second
+
+    out = {
+        "metric": "audio-sec/wall-sec (RTF^-1) with ms/utterance, Piper VITS en_GB-medium geometry, scale-bench factor",
+        "value": round(value, 3),
+        "unit": "audio-sec/wall-sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_utterance": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded weights of Piper-medium geometry, fixture phoneme ids tiled, pinned 3 frames/id, injected noise)",
+        "config": {"workload": f"{args.quality} factor={args.factor}: {len(ids)} ids, {sum(dur)} frames, {n_samples} samples "
+                               f"({audio_sec:.3f} s audio) per utterance, 1 utterance per step per GPU",
+                   "factor": args.factor, "phoneme_count": len(ids), "frames": int(sum(dur)), "samples": int(n_samples),
+                   "sample_rate": sr, "parallelism": f"utterance-replicas x{world} (one-shot RCCL weight broadcast)"},
+        "gpu_ms_mean": round(float(np.mean(gpu_ms)), 4),
+    }
+    if bcast_ms is not None:
+        out["weight_broadcast_ms"] = round(bcast_ms, 3)
+        out["weight_blob_mb"] = round(n_floats * 4 / 1e6, 1)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel, measured live with HIP events on the slot's stream
+        if not args.no_profile:
+            stats = rt.profile(0, iters=10)
+            conv = [s for s in stats if s["flops"] > 0 and "rel_attention" not in s["name"] and s["name"] != "expand_noise"]
+            mfma = [s for s in conv if "conv_post" not in s["name"]]
+            tot_us = sum(s["avg_us"] for s in stats)
+            m_us, m_fl, m_by = sum(s["avg_us"] for s in mfma), sum(s["flops"] for s in mfma), sum(s["bytes"] for s in mfma)
+            achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0
+            out["roofline"] = {
+                "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_32x32x2 implicit-GEMM Conv1d/ConvTranspose1d, all launches of one utterance)",
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": len(mfma), "avg_launch_us": round(m_us / max(1, len(mfma)), 3),
+                "algorithmic_gflop_per_utterance": round(m_fl / 1e9, 3),
+                "hbm_side": {"algorithmic_GBps": round(m_by / (m_us * 1e-6) / 1e9, 1) if m_us > 0 else 0.0, "peak": HBM_PEAK_GBS},
+                "share_of_schedule_time": round(m_us / tot_us, 3) if tot_us > 0 else None,
+            }
+            all_fl = sum(s["flops"] for s in stats)
+            out["utterance_roofline"] = {
+                "algorithmic_gflop": round(all_fl / 1e9, 3), "t_min_ms_at_fp32_mfma_peak": round(all_fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 4),
+                "frac_of_peak_at_measured_latency": round(all_fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) / (ms_per_step * 1e-3), 4),
+                "n_launches": len(stats), "sum_kernel_us": round(tot_us, 1),
+            }
+            top = sorted(stats, key=lambda s: -s["avg_us"])[:8]
+            out["top_launches"] = [{"name": s["name"], "us": round(s["avg_us"], 2),
+                                    "tflops": round(s["flops"] / (s["avg_us"] * 1e-6) / 1e12, 2) if s["avg_us"] > 0 else 0} for s in top]
+        # ---- the reference's scale bench: factor 1,2,4,8 latency (warmup 3, iters 20)
+        if not args.no_scale_bench:
+            rows = []
+            for f in (1, 2, 4, 8):
+                i2, d2, n2 = utterance(f, 99 + f, cfg.inter)
+                rt.prepare(1, i2, d2, n2, 0.667)
+                for _ in range(3):
+                    rt.launch(1); rt.collect(1)
+                wall, g = [], []
+                for _ in range(20):
+                    a = time.perf_counter()
+                    rt.launch(1); rt.collect(1)
+                    wall.append((time.perf_counter() - a) * 1e3)
+                    g.append(rt.last_gpu_ms(1))
+                asec = rt.num_samples(i2, d2) / sr
+                rows.append({"factor": f, "phoneme_count": len(i2), "ms_mean": round(float(np.mean(wall)), 4),
+                             "ms_p50": round(percentile(wall, 50), 4), "ms_p95": round(percentile(wall, 95), 4),
+                             "ms_max": round(max(wall), 4), "audio_sec": round(asec, 3),
+                             "rtf_inv": round(asec / (float(np.mean(wall)) * 1e-3), 1), "gpu_ms_mean": round(float(np.mean(g)), 4)})
+            out["scale_bench"] = rows
+            # side metric: several utterances in flight on independent slots (streams) of one GPU
+            S = max(1, min(args.slots, 12))
+            for s in range(S):
+                i2, d2, n2 = utterance(args.factor, 500 + s, cfg.inter)
+                rt.prepare(2 + s, i2, d2, n2, 0.667)
+            for _ in range(2):
+                for s in range(S):
+                    rt.launch(2 + s)
+                for s in range(S):
+                    rt.collect(2 + s)
+            reps = 10
+            a = time.perf_counter()
+            for _ in range(reps):
+                for s in range(S):
+                    rt.launch(2 + s)
+                for s in range(S):
+                    rt.collect(2 + s)
+            dt = time.perf_counter() - a
+            out["batch_throughput"] = {"slots_in_flight": S, "utterances_per_sec": round(reps * S / dt, 1),
+                                       "audio_sec_per_wall_sec": round(reps * S * audio_sec / dt, 1)}
+        # ---- CPU baseline: the oracle (C restatement, OpenMP) on the same workload, bounded sample
+        if not args.no_cpu_baseline and world == 1:
+            import oracle as orc
+            blob = ph.synthetic_blob(cfg, 1234)
+            cores = os.cpu_count() or 1
+            orc.synthesize(cfg, blob, FIXTURE_IDS, [3] * 14, None, 0.667)  # warm the library
+            reps = 1
+            a = time.perf_counter()
+            for _ in range(reps):
+                orc.synthesize(cfg, blob, ids, dur, noise, 0.667)
+            dt = (time.perf_counter() - a) / reps
+            out["cpu_baseline"] = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
+                                   "cores": cores, "kind": "port",
+                                   "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
+        print(json.dumps(out))
+    rt.close()
+    backend.close()
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   for (int idx = tid; idx < R * W; idx += kBlock) {
     const int r = idx / W, m = idx - r * W;
     float s = 0.0f;
+#pragma unroll 8
     for (int c = 0; c < d; c++) s += qs[r * d + c] * ek[m * d + c];
     qe[r * W + m] = s;
   }
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     float acc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0f;
+    // unrolled so that 8 independent k loads are in flight per thread (the loop is latency-, not bandwidth-bound)
+#pragma unroll 8
     for (int c = 0; c < d; c++) {
       const float kv = kb[(int64_t)c * T + j];
 #pragma unroll
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = 0.0f;
       const float* vr = vb + (int64_t)c * T;
+#pragma unroll 8
       for (int j = j0; j < j1; j++) {
         const float vv = vr[j];
 #pragma unroll

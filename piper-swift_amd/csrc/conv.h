@@ -49,6 +49,7 @@ struct ConvArgs {
   int wn_c = 0;  // EPI_WN_RES_SKIP split point
   // ConvTranspose (EPI_CONVT): GEMM rows = Cout_ct·ct_stride, GEMM cols = q
   int ct_stride = 0, ct_padL = 0, ct_Lout = 0;
+  int ct_shift = -1;  // log2(ct_stride) when it is a power of two (set by launch_conv_mfma)
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv

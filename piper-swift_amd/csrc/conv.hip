@@ -17,6 +17,8 @@
 //
 // Replaces conv1d_f32 / convtranspose1d_f32 (Kernels/conv1d.metal:28-71, 97-142) and their encoders
 // (MetalBackend.swift:1149-1228, 2812-2895).
+#include <type_traits>
+
 #include "conv.h"
 
 namespace ph {
@@ -49,61 +51,99 @@ __device__ __forceinline__ float load_b(const ConvArgs& p, const float* xrow, co
   return v;
 }
 
-__device__ __forceinline__ void store_elem(const ConvArgs& p, int n, int row, int col, float v) {
-  switch (p.epilogue) {
-    case EPI_STORE:
-    case EPI_RELU:
-    case EPI_TANH:
-    case EPI_RSUB: {
-      const int64_t idx = (int64_t)n * p.y_batch_stride + (int64_t)(p.out_ch_base + p.out_ch_sign * row) * p.y_len + col;
-      if (p.epilogue == EPI_RELU) v = v > 0.0f ? v : 0.0f;
-      else if (p.epilogue == EPI_TANH) v = tanhf(v);
-      else if (p.epilogue == EPI_RSUB) v = p.res[idx] - v;
-      else if (p.res) v = v + p.res[idx];
-      p.y[idx] = v;
-      break;
+// Epilogue of one output element, specialised per mode so that the (wave-uniform) mode switch happens once per tile, not
+// once per element.  Indices are 32-bit element offsets from the batch item's base (host checks they fit).
+template <int MODE>
+__device__ __forceinline__ void store_mode(const ConvArgs& p, int n, int row, int col, float v) {
+  if constexpr (MODE == EPI_STORE || MODE == EPI_RELU || MODE == EPI_TANH || MODE == EPI_RSUB) {
+    const int idx = (p.out_ch_base + p.out_ch_sign * row) * p.y_len + col;
+    float* yb = p.y + (int64_t)n * p.y_batch_stride;
+    if constexpr (MODE == EPI_RELU) v = v > 0.0f ? v : 0.0f;
+    else if constexpr (MODE == EPI_TANH) v = tanhf(v);
+    else if constexpr (MODE == EPI_RSUB) v = (p.res + (int64_t)n * p.y_batch_stride)[idx] - v;
+    else if (p.res) v = v + (p.res + (int64_t)n * p.y_batch_stride)[idx];
+    yb[idx] = v;
+  } else if constexpr (MODE == EPI_WN_RES_SKIP) {
+    if (row < p.wn_c) {
+      const int idx = row * p.y_len + col;
+      (p.y + (int64_t)n * p.y_batch_stride)[idx] = (p.res + (int64_t)n * p.y_batch_stride)[idx] + v;
+    } else {
+      const int idx = (row - p.wn_c) * p.y_len + col;
+      const float sk = p.skip ? (p.skip + (int64_t)n * p.y2_batch_stride)[idx] : 0.0f;
+      (p.y2 + (int64_t)n * p.y2_batch_stride)[idx] = sk + v;
     }
-    case EPI_WN_RES_SKIP: {
-      if (row < p.wn_c) {
-        const int64_t idx = (int64_t)n * p.y_batch_stride + (int64_t)row * p.y_len + col;
-        p.y[idx] = p.res[idx] + v;
-      } else {
-        const int64_t idx = (int64_t)n * p.y2_batch_stride + (int64_t)(row - p.wn_c) * p.y_len + col;
-        p.y2[idx] = (p.skip ? p.skip[idx] : 0.0f) + v;
-      }
-      break;
+  } else if constexpr (MODE == EPI_WN_SKIP_LAST) {
+    const int idx = row * p.y_len + col;
+    const float sk = p.skip ? (p.skip + (int64_t)n * p.y2_batch_stride)[idx] : 0.0f;
+    (p.y2 + (int64_t)n * p.y2_batch_stride)[idx] = sk + v;
+  } else if constexpr (MODE == EPI_CONVT) {
+    int co, ph;
+    if (p.ct_shift >= 0) {  // stride is a power of two in every Piper voice (8, 8, 4 / 8, 8, 2, 2)
+      co = row >> p.ct_shift;
+      ph = row & (p.ct_stride - 1);
+    } else {
+      co = row / p.ct_stride;
+      ph = row - co * p.ct_stride;
     }
-    case EPI_WN_SKIP_LAST: {
-      const int64_t idx = (int64_t)n * p.y2_batch_stride + (int64_t)row * p.y_len + col;
-      p.y2[idx] = (p.skip ? p.skip[idx] : 0.0f) + v;
-      break;
-    }
-    case EPI_CONVT: {
-      const int co = row / p.ct_stride, ph = row - co * p.ct_stride;
-      const int xo = col * p.ct_stride + ph - p.ct_padL;
-      if (xo >= 0 && xo < p.ct_Lout) p.y[(int64_t)n * p.y_batch_stride + (int64_t)co * p.y_len + xo] = v;
-      break;
-    }
+    const int xo = col * p.ct_stride + ph - p.ct_padL;
+    if (xo >= 0 && xo < p.ct_Lout) (p.y + (int64_t)n * p.y_batch_stride)[co * p.y_len + xo] = v;
   }
 }
 
-template <int NT, int KS, bool GATE, int PRO>
-__global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs p, const int nchunks, const int mtiles) {
-  constexpr int WT = 4 / KS;
+__device__ __forceinline__ void store_elem(const ConvArgs& p, int n, int row, int col, float v) {
+  switch (p.epilogue) {
+    case EPI_STORE: store_mode<EPI_STORE>(p, n, row, col, v); break;
+    case EPI_RELU: store_mode<EPI_RELU>(p, n, row, col, v); break;
+    case EPI_TANH: store_mode<EPI_TANH>(p, n, row, col, v); break;
+    case EPI_RSUB: store_mode<EPI_RSUB>(p, n, row, col, v); break;
+    case EPI_WN_RES_SKIP: store_mode<EPI_WN_RES_SKIP>(p, n, row, col, v); break;
+    case EPI_WN_SKIP_LAST: store_mode<EPI_WN_SKIP_LAST>(p, n, row, col, v); break;
+    case EPI_CONVT: store_mode<EPI_CONVT>(p, n, row, col, v); break;
+  }
+}
+
+// Contraction steps fetched per prefetch group = G(K) channel pairs × K taps (≈ 7–11 steps)
+template <int K>
+struct GroupOf {
+  static constexpr int G = K == 1 ? 8 : K == 2 ? 4 : K == 3 ? 3 : K == 5 ? 2 : 1;
+};
+
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// conv_stream_kernel<K taps, NT time tiles per wave, GATE, PRO, BT threads per block>
+//
+// Everything that is the same for the 64 lanes of a wave — tile coordinates, contraction cursor, row bases, tap
+// offsets — is kept in SGPRs (the wave id goes through readfirstlane, otherwise hipcc treats all of it as per-lane
+// 64-bit VALU arithmetic and the kernel becomes VALU-issue-bound at ~20 instructions per MFMA).  Operands come in
+// through buffer descriptors: lane part in a constant 32-bit voffset, hardware range checking makes every address
+// legal (out of range ⇒ 0), so the fetch is branch-free: per B element one v_add + one buffer_load, per A fragment one
+// buffer_load with an SGPR offset.  Zero padding inside a row is a per-lane bit mask computed once per tile and only
+// on tiles that touch a row edge.  Groups of G·K steps are double-buffered in registers (loads of group g+1 are in
+// flight while group g feeds the matrix pipe).
+template <int K, int NT, bool GATE, int PRO, int BT>
+__global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const int nchunks, const int mtiles, const int ks_log2,
+                                                         const int ngroups) {
+  constexpr int G = GroupOf<K>::G, S = G * K;
   constexpr int NA = GATE ? 2 : 1;
+  constexpr int NX = (PRO == PRO_AVG3_LRELU) ? 3 : 1;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [KS-1][WT][NA][NT][16][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tw = wave / KS, ks = wave - tw * KS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int KS = 1 << ks_log2;
+  const int WT = (BT / 64) >> ks_log2;
+  const int tw = wave >> ks_log2, ks = wave & (KS - 1);
   const int n = blockIdx.y;
   const int mt_eff = GATE ? mtiles / 2 : mtiles;
-  const int64_t tile = (int64_t)blockIdx.x * WT + tw;
-  const bool active = tile < (int64_t)mt_eff * nchunks;
-  const int mt = active ? (int)(tile % mt_eff) : 0;
-  const int chunk = active ? (int)(tile / mt_eff) : 0;
+  const int tile = (int)blockIdx.x * WT + tw;
+  const bool active = tile < mt_eff * nchunks;
+  const int mt = active ? tile % mt_eff : 0;
+  const int chunk = active ? tile / mt_eff : 0;
   const int t0 = chunk * 32 * NT;
   const int j = lane & 31, kk = lane >> 5;
   const int ncp = (p.Cin + 1) >> 1;
-  const int nsteps = ncp * p.K;
+  const int nsteps = ngroups * S;  // packed steps per row tile (zero-padded to whole groups)
   const int brow = p.ct_stride > 0 ? p.ct_stride : 1;  // bias index = row / brow
 
   f32x16 acc[NA][NT];
@@ -120,42 +160,105 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs p, con
   }
 
   if (active) {
-    const int cp_begin = (int)((int64_t)ncp * ks / KS), cp_end = (int)((int64_t)ncp * (ks + 1) / KS);
-    const float* xb = p.x + (int64_t)n * p.x_batch_stride;
-    const float* x2b = PRO == PRO_AVG3_LRELU ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
-    const float* x3b = PRO == PRO_AVG3_LRELU ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
-    const float* wa = p.w + ((int64_t)mt * nsteps) * 64 + lane;
-    const float* wb = GATE ? p.w + ((int64_t)(mt + mt_eff) * nsteps) * 64 + lane : nullptr;
-    for (int cp = cp_begin; cp < cp_end; cp++) {
-      const int ci = 2 * cp + kk;
-      const bool ch_ok = ci < p.Cin;
-      const int64_t roff = (int64_t)(p.in_ch_base + p.in_ch_sign * (ch_ok ? ci : 0)) * p.Lin;
-      const float* xrow = xb + roff;
-      const float* x2row = PRO == PRO_AVG3_LRELU ? x2b + roff : nullptr;
-      const float* x3row = PRO == PRO_AVG3_LRELU ? x3b + roff : nullptr;
-      const int step0 = cp * p.K;
-      for (int tap = 0; tap < p.K; tap++) {
-        const float a0 = wa[(int64_t)(step0 + tap) * 64];
-        float a1 = 0.0f;
-        if constexpr (GATE) a1 = wb[(int64_t)(step0 + tap) * 64];
-        const int base = t0 + j + tap * p.dil - p.padL;
-        float bv[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) bv[nt] = load_b<PRO>(p, xrow, x2row, x3row, base + 32 * nt, ch_ok);
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[nt], acc[0][nt], 0, 0, 0);
-          if constexpr (GATE) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nt], acc[1][nt], 0, 0, 0);
-        }
-      }
+    const int g_begin = (int)(((int64_t)ngroups * ks) >> ks_log2), g_end = (int)(((int64_t)ngroups * (ks + 1)) >> ks_log2);
+    const int xbytes = (int)(p.x_batch_stride * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * p.x_batch_stride), 0, xbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx2 = rx, rx3 = rx;
+    if constexpr (NX == 3) {
+      rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2 + (int64_t)n * p.x_batch_stride), 0, xbytes, 0x00020000);
+      rx3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x3 + (int64_t)n * p.x_batch_stride), 0, xbytes, 0x00020000);
     }
+    const int wbytes = nsteps * 256;
+    const __amdgpu_buffer_rsrc_t rwa = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)mt * nsteps * 64), 0, wbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rwb = rwa;
+    if constexpr (GATE) rwb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)(mt + mt_eff) * nsteps * 64), 0, wbytes, 0x00020000);
+    // lane parts of the addresses (bytes). Rows of a channel pair: {r0, r0+1}; with a reversed channel map the pair is
+    // stored in descending order, so lane half kk picks row (1−kk) and r0 is lowered by one.
+    const int rowsel = p.in_ch_sign > 0 ? kk : 1 - kk;
+    const int voffB = (rowsel * p.Lin + j) * 4;
+    const int voffA = lane * 4;
+    const int row_adj = p.in_ch_sign > 0 ? 0 : -1;
+    const int tb = t0 - p.padL;
+    // does any element of this tile's window fall outside [0, Lin)?  (wave-uniform)
+    const int span_lo = tb + (p.dil < 0 ? (K - 1) * p.dil : 0), span_hi = tb + (p.dil > 0 ? (K - 1) * p.dil : 0) + 32 * NT - 1;
+    const bool interior = span_lo >= 0 && span_hi < p.Lin;
+
+    auto body = [&](auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      // bit (k·NT + nt) of okbits: this lane's element of tap k / time tile nt lies inside the row
+      unsigned long long okbits = ~0ull;
+      if constexpr (EDGE) {
+        okbits = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const int pos = tb + k * p.dil + 32 * nt + j;
+            if (pos >= 0 && pos < p.Lin) okbits |= 1ull << (k * NT + nt);
+          }
+      }
+      float av[2][NA][S], bv[2][NX][S][NT];
+      auto fetch = [&](auto slot_tag, const int g) {
+        constexpr int sl = decltype(slot_tag)::value;
+#pragma unroll
+        for (int gi = 0; gi < G; gi++) {
+          const int cp = g * G + gi;
+          const int cpc = cp < ncp ? cp : ncp - 1;  // padded steps carry zero weights; keep their rows legal
+          const int rowbase = (p.in_ch_base + p.in_ch_sign * 2 * cpc + row_adj) * p.Lin + tb;
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            const int st = gi * K + k;
+            const int soffA = (g * S + st) * 256;
+            av[sl][0][st] = bload(rwa, voffA, soffA);
+            if constexpr (GATE) av[sl][1][st] = bload(rwb, voffA, soffA);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+              const int off = voffB + (rowbase + k * p.dil + 32 * nt) * 4;
+              bv[sl][0][st][nt] = bload(rx, off, 0);
+              if constexpr (NX == 3) {
+                bv[sl][1][st][nt] = bload(rx2, off, 0);
+                bv[sl][2][st][nt] = bload(rx3, off, 0);
+              }
+            }
+          }
+        }
+      };
+      auto compute = [&](auto slot_tag) {
+        constexpr int sl = decltype(slot_tag)::value;
+#pragma unroll
+        for (int st = 0; st < S; st++) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int k = st % K;
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            float v = bv[sl][0][st][nt];
+            if constexpr (NX == 3) v = ((v + bv[sl][1][st][nt]) + bv[sl][2][st][nt]) / 3.0f;
+            if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
+            if constexpr (EDGE) v = ((okbits >> (k * NT + nt)) & 1ull) ? v : 0.0f;
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][0][st], v, acc[0][nt], 0, 0, 0);
+            if constexpr (GATE) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][1][st], v, acc[1][nt], 0, 0, 0);
+          }
+        }
+      };
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      if (g_begin < g_end) fetch(S0{}, g_begin);
+      for (int g = g_begin; g < g_end; g += 2) {
+        if (g + 1 < g_end) fetch(S1{}, g + 1);
+        compute(S0{});
+        if (g + 2 < g_end) fetch(S0{}, g + 2);
+        if (g + 1 < g_end) compute(S1{});
+      }
+    };
+    if (interior) body(std::false_type{});
+    else body(std::true_type{});
   }
 
-  if constexpr (KS > 1) {
-    // fixed-order reduction: slice 0 + slice 1 + … (deterministic)
+  if (KS > 1) {  // fixed-order reduction over the contraction slices: slice 0 + slice 1 + … (deterministic)
     constexpr int per_wave = NA * NT * 16 * 64;
     if (ks > 0) {
-      float* dst = red + ((int64_t)((ks - 1) * WT + tw)) * per_wave + lane;
+      float* dst = red + (int64_t)((ks - 1) * WT + tw) * per_wave + lane;
 #pragma unroll
       for (int a = 0; a < NA; a++)
 #pragma unroll
@@ -165,9 +268,8 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs p, con
     }
     __syncthreads();
     if (ks == 0) {
-#pragma unroll
-      for (int s = 1; s < KS; s++) {
-        const float* src = red + ((int64_t)((s - 1) * WT + tw)) * per_wave + lane;
+      for (int s2 = 1; s2 < KS; s2++) {
+        const float* src = red + (int64_t)((s2 - 1) * WT + tw) * per_wave + lane;
 #pragma unroll
         for (int a = 0; a < NA; a++)
 #pragma unroll
@@ -180,18 +282,30 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs p, con
 
   if (!active || ks != 0) return;
   const int rows_out = GATE ? p.Cout / 2 : p.Cout;
+  auto emit = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) {
-    const int col = t0 + 32 * nt + j;
-    if (col >= p.Lout) continue;
+    for (int nt = 0; nt < NT; nt++) {
+      const int col = t0 + 32 * nt + j;
+      if (col >= p.Lout) continue;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = mt * 32 + acc_row(r, lane);
-      if (row >= rows_out) continue;
-      float v = acc[0][nt][r];
-      if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
-      store_elem(p, n, row, col, v);
+      for (int r = 0; r < 16; r++) {
+        const int row = mt * 32 + acc_row(r, lane);
+        if (row >= rows_out) continue;
+        float v = acc[0][nt][r];
+        if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
+        store_mode<MODE>(p, n, row, col, v);
+      }
     }
+  };
+  switch (p.epilogue) {  // wave-uniform
+    case EPI_STORE: emit(std::integral_constant<int, EPI_STORE>{}); break;
+    case EPI_RELU: emit(std::integral_constant<int, EPI_RELU>{}); break;
+    case EPI_TANH: emit(std::integral_constant<int, EPI_TANH>{}); break;
+    case EPI_RSUB: emit(std::integral_constant<int, EPI_RSUB>{}); break;
+    case EPI_WN_RES_SKIP: emit(std::integral_constant<int, EPI_WN_RES_SKIP>{}); break;
+    case EPI_WN_SKIP_LAST: emit(std::integral_constant<int, EPI_WN_SKIP_LAST>{}); break;
+    case EPI_CONVT: emit(std::integral_constant<int, EPI_CONVT>{}); break;
   }
 }
 
@@ -203,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restri
     const int lane = (int)(i & 63);
     const int64_t ms = i >> 6;
     const int step = (int)(ms % nsteps), mt = (int)(ms / nsteps);
-    const int cp = step / K, tap = step - cp * K;
+    const int cp = step / K, tap = step - cp * K;  // steps beyond the real channel pairs are zero padding
     const int co = mt * 32 + (lane & 31), ci = 2 * cp + (lane >> 5);
     out[i] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * K + tap] : 0.0f;
   }
@@ -286,33 +400,72 @@ __global__ __launch_bounds__(kBlock) void convt_direct_kernel(const float* __res
   }
 }
 
-template <int NT, int KS, bool GATE>
-void launch_variant(hipStream_t s, const ConvArgs& a, int nchunks, int mtiles, dim3 grid, size_t lds) {
-  switch (a.prologue) {
-    case PRO_NONE:
-      hipLaunchKernelGGL((conv_mfma_kernel<NT, KS, GATE, PRO_NONE>), grid, dim3(kBlock), lds, s, a, nchunks, mtiles);
-      break;
-    case PRO_LRELU:
-      hipLaunchKernelGGL((conv_mfma_kernel<NT, KS, GATE, PRO_LRELU>), grid, dim3(kBlock), lds, s, a, nchunks, mtiles);
-      break;
-    default:
-      hipLaunchKernelGGL((conv_mfma_kernel<NT, KS, GATE, PRO_AVG3_LRELU>), grid, dim3(kBlock), lds, s, a, nchunks, mtiles);
-      break;
+// tap counts with a compiled streaming kernel (Piper: 1, 3, 5, 7, 11; ConvTranspose phases: 2)
+inline bool k_supported(int K) { return K == 1 || K == 2 || K == 3 || K == 5 || K == 7 || K == 11; }
+inline int group_of(int K) { return K == 1 ? 8 : K == 2 ? 4 : K == 3 ? 3 : K == 5 ? 2 : 1; }
+inline int padded_steps(int Cin, int K) {
+  const int ncp = (Cin + 1) / 2, G = group_of(K);
+  return (int)ceil_div(ncp, G) * G * K;
+}
+
+template <int K, int NT, bool GATE, int PRO, int BT>
+void launch_one(hipStream_t s, const ConvArgs& a, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid, size_t lds) {
+  if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS once per instantiation
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)conv_stream_kernel<K, NT, GATE, PRO, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      configured = true;
+    }
   }
+  hipLaunchKernelGGL((conv_stream_kernel<K, NT, GATE, PRO, BT>), grid, dim3(BT), lds, s, a, nchunks, mtiles, ks_log2, ngroups);
+}
+
+template <int K, bool GATE, int PRO>
+bool launch_shape(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid,
+                  size_t lds) {
+  if (BT == 256) {
+    if (NT == 1) { launch_one<K, 1, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    if (NT == 2) { launch_one<K, 2, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    if constexpr (!GATE && PRO != PRO_AVG3_LRELU)
+      if (NT == 4) { launch_one<K, 4, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    return false;
+  }
+  if (NT != 1) return false;
+  if (BT == 512) { launch_one<K, 1, GATE, PRO, 512>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+  if constexpr (!GATE)
+    if (BT == 1024) { launch_one<K, 1, GATE, PRO, 1024>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+  return false;
+}
+
+// which (K, GATE, PRO) combinations are compiled: every conv of the Piper graph + the op-level API's plain convs
+template <int K>
+bool launch_k(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid,
+              size_t lds) {
+  if (a.gate) {
+    if (a.prologue != PRO_NONE) return false;
+    return launch_shape<K, true, PRO_NONE>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+  }
+  switch (a.prologue) {
+    case PRO_NONE: return launch_shape<K, false, PRO_NONE>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+    case PRO_LRELU: return launch_shape<K, false, PRO_LRELU>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+    case PRO_AVG3_LRELU:
+      if constexpr (K == 2 || K == 1) return launch_shape<K, false, PRO_AVG3_LRELU>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+      return false;
+  }
+  return false;
 }
 
 }  // namespace
 
-size_t packed_conv_floats(int Cout, int Cin, int K) {
-  return (size_t)ceil_div(Cout, 32) * (size_t)(((Cin + 1) / 2) * K) * 64;
-}
+size_t packed_conv_floats(int Cout, int Cin, int K) { return (size_t)ceil_div(Cout, 32) * (size_t)padded_steps(Cin, K) * 64; }
 size_t packed_convt_floats(int Cin, int Cout, int K, int s) {
   const int J = (K + s - 1) / s;
-  return (size_t)ceil_div((int64_t)Cout * s, 32) * (size_t)(((Cin + 1) / 2) * J) * 64;
+  return (size_t)ceil_div((int64_t)Cout * s, 32) * (size_t)padded_steps(Cin, J) * 64;
 }
 
 int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed) {
-  const int mtiles = (int)ceil_div(Cout, 32), nsteps = ((Cin + 1) / 2) * K;
+  const int mtiles = (int)ceil_div(Cout, 32), nsteps = padded_steps(Cin, K);
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
@@ -322,7 +475,7 @@ int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, f
 
 int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed) {
   const int J = (K + stride - 1) / stride;
-  const int mtiles = (int)ceil_div((int64_t)Cout * stride, 32), nsteps = ((Cin + 1) / 2) * J;
+  const int mtiles = (int)ceil_div((int64_t)Cout * stride, 32), nsteps = padded_steps(Cin, J);
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
@@ -331,38 +484,54 @@ int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, 
 }
 
 bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups) {
-  return stride == 1 && groups == 1 && Cout >= 8 && Cin >= 2 && K >= 1;
+  return stride == 1 && groups == 1 && Cout >= 8 && Cin >= 2 && k_supported(K);
 }
 
-int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
+int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
+  ConvArgs a = a_in;
+  a.ct_shift = -1;
+  if (a.ct_stride > 0 && (a.ct_stride & (a.ct_stride - 1)) == 0) a.ct_shift = __builtin_ctz((unsigned)a.ct_stride);
   if (a.N <= 0 || a.Lout <= 0 || a.Cout <= 0) return PIPER_HIP_OK;
+  if (a.Lin < 1) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv_mfma: empty input rows must take the direct path");
   if (a.N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: batch %d too large", a.N);
+  if (!k_supported(a.K)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: no streaming kernel for %d taps", a.K);
   if (a.gate && (a.Cout % 64)) PH_FAIL(PIPER_HIP_ERR_SHAPE, "gated conv needs Cout %% 64 == 0 (got %d)", a.Cout);
+  if (a.x_batch_stride * 4 > 0x7fffffffLL) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: input larger than 2 GiB per batch item");
   const int mtiles = (int)ceil_div(a.Cout, 32);
   const int mt_eff = a.gate ? mtiles / 2 : mtiles;
-  const int ncp = (a.Cin + 1) / 2;
+  const int G = group_of(a.K);
+  const int ngroups = (int)ceil_div((a.Cin + 1) / 2, G);
   // tile shape: give every SIMD (4 per CU) a wave before growing the per-wave tile
   const int64_t want = (int64_t)ctx->num_cus * 4;
   int NT = 4;
   auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, 32 * nt) * a.N; };
   while (NT > 1 && waves(NT) < want) NT >>= 1;
-  if (a.gate && NT > 2) NT = 2;  // 2 accumulator sets per time tile
-  int KS = 1;
-  while (KS < 4 && waves(NT) * KS < want && ncp / (KS * 2) >= 8) KS <<= 1;
+  if ((a.gate || a.prologue == PRO_AVG3_LRELU) && NT > 2) NT = 2;  // register budget: 2 accumulator sets / 3 raw inputs
+  if (a.K >= 11 && NT > 2) NT = 2;
+  // Split the contraction over KS waves of one block while SIMDs would otherwise idle and every slice keeps ≥ 2 prefetch
+  // groups: short utterances have tiny outputs and long contractions, so this is their only parallelism.
+  int ks_log2 = 0;
+  const int ks_cap = a.gate ? 3 : 4;  // the gated tile holds two accumulator sets: 512 threads keep it in 256 VGPRs
+  while (ks_log2 < ks_cap && waves(NT) * (1 << ks_log2) < want && ngroups / (2 << ks_log2) >= 2 && NT == 1) ks_log2++;
+  const int KS = 1 << ks_log2;
+  const int BT = KS <= 4 ? 256 : 64 * KS;
+  const int WT = (BT / 64) / KS;
   const int nchunks = (int)ceil_div(a.Lout, 32 * NT);
-  const int WT = 4 / KS;
   const int64_t tiles = (int64_t)mt_eff * nchunks;
+  if (tiles > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: too many tiles");
   dim3 grid((unsigned)ceil_div(tiles, WT), (unsigned)a.N);
   const int NA = a.gate ? 2 : 1;
   const size_t lds = KS > 1 ? (size_t)(KS - 1) * WT * NA * NT * 16 * 64 * sizeof(float) : 0;
-#define PH_CASE(NTV, KSV)                                                                      \
-  if (NT == NTV && KS == KSV) {                                                                \
-    if (a.gate) launch_variant<NTV, KSV, true>(s, a, nchunks, mtiles, grid, lds);              \
-    else launch_variant<NTV, KSV, false>(s, a, nchunks, mtiles, grid, lds);                    \
+  bool ok = false;
+  switch (a.K) {
+    case 1: ok = launch_k<1>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    case 2: ok = launch_k<2>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    case 3: ok = launch_k<3>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    case 5: ok = launch_k<5>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    case 7: ok = launch_k<7>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    case 11: ok = launch_k<11>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
   }
-  PH_CASE(1, 1) PH_CASE(1, 2) PH_CASE(1, 4) PH_CASE(2, 1) PH_CASE(2, 2) PH_CASE(2, 4) PH_CASE(4, 1)
-#undef PH_CASE
-  if (NT == 4 && KS != 1) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv: internal tiling error");
+  if (!ok) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: variant K=%d NT=%d gate=%d prologue=%d not compiled", a.K, NT, a.gate, a.prologue);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_mfma launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;

@@ -256,21 +256,36 @@ __global__ __launch_bounds__(kBlock) void softmax_block_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------- channel LayerNorm with fused residual
-// x,y [N,C,T]; normalise over C for each (n,t). Block = 32 time steps × 8 channel lanes; x is read coalesced along t.
-constexpr int kLnT = 32, kLnG = 8;
+// x,y [N,C,T]; normalise over C for each (n,t). Block = 16 time steps × 16 channel lanes.  Every thread first issues ALL
+// of its loads (≤ 2·kLnMaxV independent requests in flight), keeps x+y in registers, and the two reductions go through
+// LDS — one memory round trip instead of three dependent passes (at T≈100 the op is pure latency, not bandwidth).
+constexpr int kLnT = 16, kLnG = 16, kLnMaxV = 32;  // C ≤ kLnG·kLnMaxV = 512
 __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float* __restrict__ out, int64_t C, int64_t T, float eps) {
+                                                               float* __restrict__ out, int C, int T, float eps) {
   __shared__ float red[kLnG][kLnT + 1];
   const int tt = threadIdx.x % kLnT, g = threadIdx.x / kLnT;
   const int64_t n = blockIdx.y;
-  const int64_t t = (int64_t)blockIdx.x * kLnT + tt;
+  const int t = blockIdx.x * kLnT + tt;
   const bool ok = t < T;
-  const float* xb = x + n * C * T;
-  const float* yb = y ? y + n * C * T : nullptr;
+  const float* xb = x + n * (int64_t)C * T;
+  const float* yb = y ? y + n * (int64_t)C * T : nullptr;
+  float v[kLnMaxV], w[kLnMaxV];
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; i++) {
+    const int c = g + kLnG * i;
+    const bool in = ok && c < C;
+    const int64_t idx = in ? (int64_t)c * T + t : 0;
+    v[i] = xb[idx];
+    w[i] = yb ? yb[idx] : 0.0f;
+  }
   float s = 0.0f;
-  if (ok)
-    for (int64_t c = g; c < C; c += kLnG) s += xb[c * T + t] + (yb ? yb[c * T + t] : 0.0f);
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; i++) {
+    const int c = g + kLnG * i;
+    v[i] = (ok && c < C) ? v[i] + w[i] : 0.0f;
+    s += v[i];
+  }
   red[g][tt] = s;
   __syncthreads();
   float mean = 0.0f;
@@ -279,11 +294,13 @@ __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __re
   mean = mean / (float)C;
   __syncthreads();
   float q = 0.0f;
-  if (ok)
-    for (int64_t c = g; c < C; c += kLnG) {
-      const float d = (xb[c * T + t] + (yb ? yb[c * T + t] : 0.0f)) - mean;
-      q += d * d;
-    }
+#pragma unroll
+  for (int i = 0; i < kLnMaxV; i++) {
+    const int c = g + kLnG * i;
+    const float d = (c < C) ? v[i] - mean : 0.0f;
+    v[i] = d;
+    q += d * d;
+  }
   red[g][tt] = q;
   __syncthreads();
   float var = 0.0f;
@@ -291,10 +308,51 @@ __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __re
   for (int i = 0; i < kLnG; i++) var += red[i][tt];
   var = var / (float)C;
   const float sd = sqrtf(var + eps);
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < kLnMaxV; i++) {
+      const int c = g + kLnG * i;
+      if (c < C) out[n * (int64_t)C * T + (int64_t)c * T + t] = (v[i] / sd) * gamma[c] + beta[c];
+    }
+  }
+}
+
+// any C: three strided passes (only used when C > 512)
+__global__ __launch_bounds__(kBlock) void add_layernorm_big_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ out, int C, int T, float eps) {
+  __shared__ float red[kLnG][kLnT + 1];
+  const int tt = threadIdx.x % kLnT, g = threadIdx.x / kLnT;
+  const int64_t n = blockIdx.y;
+  const int t = blockIdx.x * kLnT + tt;
+  const bool ok = t < T;
+  const float* xb = x + n * (int64_t)C * T;
+  const float* yb = y ? y + n * (int64_t)C * T : nullptr;
+  float s = 0.0f;
   if (ok)
-    for (int64_t c = g; c < C; c += kLnG) {
-      const float d = (xb[c * T + t] + (yb ? yb[c * T + t] : 0.0f)) - mean;
-      out[n * C * T + c * T + t] = (d / sd) * gamma[c] + beta[c];
+    for (int c = g; c < C; c += kLnG) s += xb[(int64_t)c * T + t] + (yb ? yb[(int64_t)c * T + t] : 0.0f);
+  red[g][tt] = s;
+  __syncthreads();
+  float mean = 0.0f;
+  for (int i = 0; i < kLnG; i++) mean += red[i][tt];
+  mean = mean / (float)C;
+  __syncthreads();
+  float q = 0.0f;
+  if (ok)
+    for (int c = g; c < C; c += kLnG) {
+      const float d = (xb[(int64_t)c * T + t] + (yb ? yb[(int64_t)c * T + t] : 0.0f)) - mean;
+      q += d * d;
+    }
+  red[g][tt] = q;
+  __syncthreads();
+  float var = 0.0f;
+  for (int i = 0; i < kLnG; i++) var += red[i][tt];
+  var = var / (float)C;
+  const float sd = sqrtf(var + eps);
+  if (ok)
+    for (int c = g; c < C; c += kLnG) {
+      const float d = (xb[(int64_t)c * T + t] + (yb ? yb[(int64_t)c * T + t] : 0.0f)) - mean;
+      out[n * (int64_t)C * T + (int64_t)c * T + t] = (d / sd) * gamma[c] + beta[c];
     }
 }
 
@@ -680,8 +738,12 @@ PH_EXPORT int piper_hip_add_layernorm_f32(piper_hip_ctx* ctx, const float* x, co
   if (n * t == 0) return PIPER_HIP_OK;
   if (!x || !gamma || !beta) PH_FAIL(PIPER_HIP_ERR_ARG, "add_layernorm: null input");
   ph::StreamScope ss(ctx, stream);
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)ph::ceil_div(t, kLnT), (unsigned)n), dim3(kBlock), 0, ss.s, x, y,
-                     gamma, beta, *out, c, t, eps);
+  if (c * t > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "add_layernorm: tensor too large");
+  const dim3 grid((unsigned)ph::ceil_div(t, kLnT), (unsigned)n);
+  if (c <= kLnG * kLnMaxV)
+    hipLaunchKernelGGL(add_layernorm_kernel, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_big_kernel, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
   return ss.finish("add_layernorm_f32");
 }
 

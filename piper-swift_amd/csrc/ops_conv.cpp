@@ -50,7 +50,7 @@ PH_EXPORT int piper_hip_conv1d_f32(piper_hip_ctx* ctx, const float* x, const int
   a.N = (int)N; a.Cin = (int)Cin; a.Cout = (int)Cout; a.K = (int)K; a.dil = p->dilation; a.padL = p->pad_l;
   a.Lin = (int)Lin; a.Lout = (int)Lout; a.stride = p->stride; a.groups = (int)g;
   a.x_batch_stride = Cin * Lin; a.y_batch_stride = Cout * Lout; a.y_len = (int)Lout;
-  if (conv_mfma_eligible((int)Cout, (int)Cin, (int)K, p->stride, (int)g)) {
+  if (Lin >= 1 && conv_mfma_eligible((int)Cout, (int)Cin, (int)K, p->stride, (int)g)) {
     float* packed = nullptr;
     rc = pool_floats(ctx, packed_conv_floats((int)Cout, (int)Cin, (int)K), &packed);
     if (rc) return rc;

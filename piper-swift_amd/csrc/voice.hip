@@ -49,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict
 // m_p/logs_p expansion by the one-hot path matrix (MatMul [1,F,T]×[1,T,I], GraphExecutor.swift:1862-1915) is a row
 // gather: frame f copies phoneme t(f); bit-identical to the matmul (every other product is an exact ±0 add).
 __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __restrict__ stats, const int32_t* __restrict__ frame2id,
-                                                              const float* __restrict__ noise, float* __restrict__ zp, int I, int T,
-                                                              int F, const float* __restrict__ noise_scale_dev) {
+                                                              const float* __restrict__ noise, float* __restrict__ zp, float* __restrict__ zp_tap,
+                                                              int I, int T, int F, const float* __restrict__ noise_scale_dev) {
   const float noise_scale = noise_scale_dev[0];  // per-utterance scalar lives in device memory so a replayed graph sees it
   const int64_t total = (int64_t)I * F;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __res
     const float m = stats[(int64_t)c * T + t];
     const float lg = stats[(int64_t)(I + c) * T + t];
     const float nz = noise[i];
-    zp[i] = m + (nz * expf(lg)) * noise_scale;
+    const float r = m + (nz * expf(lg)) * noise_scale;
+    zp[i] = r;      // updated in place by the flow couplings
+    zp_tap[i] = r;  // pristine copy for the "z_p" debug tap
   }
 }
 
@@ -351,6 +353,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
   float* stats = ar.f32((size_t)2 * I * T);
   float* zp = ar.f32((size_t)I * F);
   float* zflip = ar.f32((size_t)I * F);
+  float* zp_tap = ar.f32((size_t)I * F);
   float* h = ar.f32((size_t)H * F);
   float* acts = ar.f32((size_t)H * F);
   float* skip = ar.f32((size_t)H * F);
@@ -429,7 +432,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     const float* nsd = s.noise_scale;
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
-      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid), dim3(kBlock), 0, q, stats, f2i, nz, zp, I, T, F, nsd);
+      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd);
       return PIPER_HIP_OK;
     };
     // path expansion counted as the reference's two MatMuls mm(1,F,192,T)
@@ -437,7 +440,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     st.bytes = 2.0 * 4.0 * ((double)F * T + (double)T * I + (double)F * I);
     s.steps.push_back(st);
   }
-  s.taps["z_p"] = {zp, (size_t)I * F};
+  s.taps["z_p"] = {zp_tap, (size_t)I * F};
   // ---------------- flow (reverse)
   bool flipped = false;
   const int half = I / 2;

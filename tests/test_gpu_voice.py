@@ -1,0 +1,181 @@
+"""GPU: whole-utterance path (piper_hip_voice_*) vs oracle, golden vectors and size-independent properties."""
+import numpy as np
+import pytest
+
+import katdata as kd
+import oracle as orc
+import piper_hip as ph
+from conftest import OP_TOL, WAVE_TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+SD = kd.case_seed("mod", 0)
+
+
+@pytest.fixture(scope="module")
+def rt_medium(backend, voices):
+    cfg, blob = voices["medium"]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    yield rt
+    rt.close()
+
+
+def run_with_taps(rt, ids, dur, noise, ns=0.667, slot=0):
+    rt.prepare(slot, ids, dur, noise, ns)
+    rt.launch(slot)
+    audio = rt.collect(slot)
+    T, F = len(ids), int(np.sum(dur))
+    I, H = rt.cfg.inter, rt.cfg.hidden
+    taps = {n: rt.tap(slot, n, sz) for n, sz in (("enc_out", H * T), ("m_p", I * T), ("logs_p", I * T), ("z_p", I * F), ("z", I * F))}
+    return audio, taps
+
+
+def test_factor1_vs_golden_and_oracle(rt_medium, golden_mods, voices):
+    cfg, blob = voices["medium"]
+    ids, dur = kd.FIXTURE_IDS, [3] * 14
+    noise = kd.sym(SD + 80, (192, 42), 1.7320508)
+    audio, taps = run_with_taps(rt_medium, ids, dur, noise)
+    ref_audio, ref_taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+    for k in ("enc_out", "m_p", "logs_p", "z_p", "z"):
+        assert_close(taps[k], ref_taps[k], OP_TOL, k + " vs oracle")
+        assert_close(taps[k], golden_mods["synth_f1." + k], OP_TOL, k + " vs golden")
+    assert audio.size == 42 * 256 == rt_medium.num_samples(ids, dur)
+    assert_close(audio, ref_audio, WAVE_TOL, "audio vs oracle")
+    assert_close(audio, golden_mods["synth_f1.audio"], WAVE_TOL, "audio vs golden")
+
+
+def test_ragged_durations(rt_medium, golden_mods):
+    dur = [0, 5, 1, 2, 0, 4, 3, 1, 2, 6, 0, 1, 2, 3]
+    noise = kd.sym(SD + 81, (192, sum(dur)), 1.7320508)
+    audio, taps = run_with_taps(rt_medium, kd.FIXTURE_IDS, dur, noise)
+    assert_close(taps["z"], golden_mods["synth_ragged.z"], OP_TOL)
+    assert_close(audio, golden_mods["synth_ragged.audio"], WAVE_TOL)
+
+
+def test_synthesize_api_and_no_noise(rt_medium, voices):
+    cfg, blob = voices["medium"]
+    ids, dur = [1, 20, 0, 120, 2], [2, 1, 3, 1, 2]
+    a = rt_medium.synthesize(ids, dur, None, 0.667)  # noise NULL ⇒ zeros
+    assert_close(a, orc.synthesize(cfg, blob, ids, dur, None, 0.667), WAVE_TOL)
+    # the same (T,F) again with a different noise scale must not replay stale scalars from the captured graph
+    nz = kd.sym(9, (192, 9), 1.0)
+    b1 = rt_medium.synthesize(ids, dur, nz, 0.25)
+    assert_close(b1, orc.synthesize(cfg, blob, ids, dur, nz, 0.25), WAVE_TOL)
+    b2 = rt_medium.synthesize(ids, dur, nz, 1.0)
+    assert_close(b2, orc.synthesize(cfg, blob, ids, dur, nz, 1.0), WAVE_TOL)
+    assert not np.array_equal(b1, b2)
+
+
+def test_factor8_vs_oracle(rt_medium, voices):
+    """BASELINE configs[1]: 112 ids, 336 frames, 86 016 samples."""
+    cfg, blob = voices["medium"]
+    ids, dur = kd.FIXTURE_IDS * 8, [3] * 112
+    noise = kd.sym(SD + 90, (192, 336), 1.7320508)
+    audio, taps = run_with_taps(rt_medium, ids, dur, noise)
+    ref_audio, ref_taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+    for k in ("enc_out", "z_p", "z"):
+        assert_close(taps[k], ref_taps[k], OP_TOL, k)
+    assert audio.size == 86016
+    assert_close(audio, ref_audio, WAVE_TOL, "audio")
+
+
+def test_errors(rt_medium):
+    with pytest.raises(ph.ShapeMismatch):
+        rt_medium.synthesize([1, 2], [0, 0])  # zero frames
+    with pytest.raises(ph.ShapeMismatch):
+        rt_medium.synthesize([1] * 5000, [1] * 5000)  # > 4096 ids (PiperCLI.swift:394)
+    with pytest.raises(ph.InvalidArgument):
+        rt_medium.launch(11)  # slot never prepared
+
+
+def op_level_generator(b, cfg, blob, z, F):
+    """The HiFi-GAN generator executed op by op through the MetalBackend-shaped API (no fused voice path)."""
+    lay = {e["name"]: e for e in ph.blob_layout(cfg)}
+
+    def W(n):
+        e = lay[n]
+        return b.uploadFloat32(blob[e["offset"]:e["offset"] + e["count"]]), e["shape"]
+
+    zd = b.uploadFloat32(z)
+    w, ws = W("dec.conv_pre.weight")
+    bias, _ = W("dec.conv_pre.bias")
+    x, shp = b.conv1dF32(zd, [1, cfg.inter, F], w, ws, bias, padL=3, padR=3)
+    ch = cfg.up_initial
+    for u in range(cfg.n_ups):
+        x = b.leakyReluF32(x, int(np.prod(shp)), 0.1)
+        w, ws = W(f"dec.ups.{u}.weight")
+        bias, _ = W(f"dec.ups.{u}.bias")
+        k, s = cfg.up_kernels[u], cfg.up_rates[u]
+        x, shp = b.convTranspose1dF32(x, shp, w, ws, bias, stride=s, padL=(k - s) // 2, padR=(k - s) // 2)
+        ch //= 2
+        xs = None
+        for j in range(cfg.n_rb):
+            rb = u * cfg.n_rb + j
+            dils = [cfg.rb_dilations[j][d] for d in range(cfg.rb_n_dil)]
+            names = []
+            for d in range(cfg.rb_n_dil):
+                names += [f"dec.resblocks.{rb}.convs1.{d}", f"dec.resblocks.{rb}.convs2.{d}"] if cfg.resblock_type == 1 \
+                    else [f"dec.resblocks.{rb}.convs.{d}"]
+            wl = [W(n + ".weight")[0] for n in names]
+            bl = [W(n + ".bias")[0] for n in names]
+            r = b.hifiganResblockF32(cfg.resblock_type, x, 1, ch, shp[2], cfg.rb_kernels[j], dils, wl, bl, 0.1)
+            xs = r if xs is None else b.addF32(xs, shp, r, shp)[0]
+        x, _ = b.divF32(xs, shp, b.uploadFloat32(np.array([cfg.n_rb], np.float32)), [1])
+    x = b.leakyReluF32(x, int(np.prod(shp)), 0.01)
+    w, ws = W("dec.conv_post.weight")
+    x, shp = b.conv1dF32(x, shp, w, ws, None, padL=3, padR=3)
+    x = b.tanhF32(x, int(np.prod(shp)))
+    return b.downloadFloat32(x, int(np.prod(shp)))
+
+
+@pytest.mark.parametrize("factor", [8, 64])
+def test_full_size_properties(factor, backend, rt_medium, voices):
+    """BASELINE full sizes (factor 64 = 896 ids, 2 688 frames, 688 128 samples) via size-independent properties:
+    (1) finite, bounded by tanh; (2) bit-identical on replay and across slots (no races, no stale state);
+    (3) the fused generator equals the op-by-op composition through the C-ABI on the same z."""
+    cfg, blob = voices["medium"]
+    T = 14 * factor
+    ids, dur = kd.FIXTURE_IDS * factor, [3] * T
+    F = 3 * T
+    noise = kd.sym(SD + 100 + factor, (192, F), 1.7320508)
+    audio, taps = run_with_taps(rt_medium, ids, dur, noise, slot=0)
+    assert audio.size == F * 256
+    assert np.all(np.isfinite(audio)) and np.max(np.abs(audio)) <= 1.0
+    assert float(np.std(audio)) > 1e-3
+    rt_medium.launch(0)
+    again = rt_medium.collect(0)
+    assert np.array_equal(audio, again), "graph replay is not deterministic"
+    other, _ = run_with_taps(rt_medium, ids, dur, noise, slot=3)
+    assert np.array_equal(audio, other), "slots disagree"
+    ref = op_level_generator(backend, cfg, blob, taps["z"], F)
+    assert_close(audio, ref, 2e-4, "fused generator vs op-level composition")
+
+
+def test_high_voice_vs_oracle(backend, voices):
+    cfg, blob = voices["high"]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        ids, dur = kd.FIXTURE_IDS, [1] * 14
+        noise = kd.sym(SD + 120, (192, 14), 1.7320508)
+        audio, taps = run_with_taps(rt, ids, dur, noise)
+        ref_audio, ref_taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+        assert_close(taps["z"], ref_taps["z"], OP_TOL)
+        assert audio.size == 14 * 256
+        assert_close(audio, ref_audio, WAVE_TOL)
+    finally:
+        rt.close()
+
+
+def test_overlapped_slots(rt_medium, voices):
+    """Several prepared utterances of different lengths launched back-to-back overlap on the GPU and stay correct."""
+    cfg, blob = voices["medium"]
+    utts = []
+    for s, f in enumerate((1, 2, 3, 1)):
+        ids, dur = kd.FIXTURE_IDS * f, [3] * (14 * f)
+        noise = kd.sym(SD + 200 + s, (192, 42 * f), 1.7320508)
+        utts.append((ids, dur, noise))
+        rt_medium.prepare(4 + s, ids, dur, noise, 0.667)
+    for s in range(4):
+        rt_medium.launch(4 + s)
+    for s, (ids, dur, noise) in enumerate(utts):
+        assert_close(rt_medium.collect(4 + s), orc.synthesize(cfg, blob, ids, dur, noise, 0.667), WAVE_TOL, f"slot {4 + s}")
