@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int R = 8;
+constexpr int kKeyTile = 128;  // keys staged per LDS tile
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -27,17 +27,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// K and V tiles are brought into LDS with one burst of independent, coalesced loads per tile (row stride TK+1 so that
+// both the per-key and the per-channel access patterns are bank-conflict-free); the dot products then run out of LDS.
+// With T ≈ 100 the op is a chain of memory round trips, so the structure minimises dependent global accesses:
+// q strip → K tile(s) → V tile(s) → store.
+template <int R>
 __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, const float* __restrict__ ek,
                                                                const float* __restrict__ ev, float* __restrict__ out, int H, int d,
                                                                int T, int w, int64_t in_batch_stride, int64_t out_batch_stride,
-                                                               int G) {
+                                                               int G, int TK) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int W = 2 * w + 1;
-  float* qs = smem;              // [R][d]
-  float* qe = qs + R * d;        // [R][W]
-  float* part = qe + R * W;      // [G][R][d]
-  float* sc = part + G * R * d;  // [R][T]
+  const int ld = TK + 1;
+  float* qs = smem;               // [R][d]
+  float* qe = qs + R * d;         // [R][W]
+  float* part = qe + R * W;       // [G][R][d]
+  float* kv = part + G * R * d;   // [d][TK+1]
+  float* sc = kv + d * ld;        // [R][T]
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * R, h = blockIdx.y, n = blockIdx.z;
   const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
@@ -60,25 +67,34 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     for (int c = 0; c < d; c++) s += qs[r * d + c] * ek[m * d + c];
     qe[r * W + m] = s;
   }
-  __syncthreads();
-  // 2. score strip: lanes along j (k rows are read coalesced), R rows per thread in registers
-  for (int j = tid; j < T; j += kBlock) {
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.0f;
-    // unrolled so that 8 independent k loads are in flight per thread (the loop is latency-, not bandwidth-bound)
-#pragma unroll 8
-    for (int c = 0; c < d; c++) {
-      const float kv = kb[(int64_t)c * T + j];
-#pragma unroll
-      for (int r = 0; r < R; r++) acc[r] = fmaf(qs[r * d + c], kv, acc[r]);
+  // 2. score strip, one key tile at a time
+  for (int j0 = 0; j0 < T; j0 += TK) {
+    const int tk = min(TK, T - j0);
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = tid; idx < d * tk; idx += kBlock) {
+      const int c = idx / tk, jj = idx - c * tk;
+      kv[c * ld + jj] = kb[(int64_t)c * T + j0 + jj];
     }
+    __syncthreads();
+    for (int jj = tid; jj < tk; jj += kBlock) {
+      float acc[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int delta = j - (i0 + r);
-      float s = acc[r];
-      if (delta >= -w && delta <= w) s += qe[r * W + delta + w];
-      sc[r * T + j] = s;
+      for (int r = 0; r < R; r++) acc[r] = 0.0f;
+#pragma unroll 4
+      for (int c = 0; c < d; c++) {
+        const float kval = kv[c * ld + jj];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = fmaf(qs[r * d + c], kval, acc[r]);
+      }
+      const int j = j0 + jj;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int delta = j - (i0 + r);
+        float sv = acc[r];
+        if (delta >= -w && delta <= w) sv += qe[r * W + delta + w];
+        sc[r * T + j] = sv;
+      }
     }
   }
   __syncthreads();
@@ -101,25 +117,33 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
       for (int j = lane; j < T; j += 64) row[j] *= inv;
     }
   }
-  __syncthreads();
-  // 4. P·V: thread = (channel c, key slice g); p comes from LDS as a broadcast
-  {
-    const int c = tid % d, g = tid / d;
-    if (g < G) {
-      const int j0 = (int)((int64_t)T * g / G), j1 = (int)((int64_t)T * (g + 1) / G);
-      float acc[R];
+  // 4. P·V: thread = (channel c, key slice g of the tile); p comes from LDS as a broadcast
+  const int c4 = tid % d, g4 = tid / d;
+  float pv[R];
 #pragma unroll
-      for (int r = 0; r < R; r++) acc[r] = 0.0f;
-      const float* vr = vb + (int64_t)c * T;
-#pragma unroll 8
-      for (int j = j0; j < j1; j++) {
-        const float vv = vr[j];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = fmaf(sc[r * T + j], vv, acc[r]);
-      }
-#pragma unroll
-      for (int r = 0; r < R; r++) part[(g * R + r) * d + c] = acc[r];
+  for (int r = 0; r < R; r++) pv[r] = 0.0f;
+  for (int j0 = 0; j0 < T; j0 += TK) {
+    const int tk = min(TK, T - j0);
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = tid; idx < d * tk; idx += kBlock) {
+      const int c = idx / tk, jj = idx - c * tk;
+      kv[c * ld + jj] = vb[(int64_t)c * T + j0 + jj];
     }
+    __syncthreads();
+    if (g4 < G) {
+      const int ja = (int)((int64_t)tk * g4 / G), jb = (int)((int64_t)tk * (g4 + 1) / G);
+#pragma unroll 4
+      for (int jj = ja; jj < jb; jj++) {
+        const float vv = kv[c4 * ld + jj];
+#pragma unroll
+        for (int r = 0; r < R; r++) pv[r] = fmaf(sc[r * T + j0 + jj], vv, pv[r]);
+      }
+    }
+  }
+  if (g4 < G) {
+#pragma unroll
+    for (int r = 0; r < R; r++) part[(g4 * R + r) * d + c4] = pv[r];
   }
   __syncthreads();
   // 5. combine slices, add the relative-value term, store [H·d, T]
@@ -150,16 +174,26 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   if (T > 4096) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: T=%d exceeds 4096 (reference max-phonemes cap)", T);
   if (H > 65535 || N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: heads/batch too large");
   const int G = kBlock / d;
-  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)R * T) * sizeof(float);
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)rel_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int TK = T < kKeyTile ? T : kKeyTile;
+  // query rows per block: fewer rows → more blocks (short utterances have only T/R·H of them); 4 rows also keeps the score
+  // strip of the longest utterances inside the 160 KiB of LDS
+  const int R = (T > 2048 || (int64_t)ceil_div(T, 8) * H * N < ctx->num_cus) ? 4 : 8;
+  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T) * sizeof(float);
+  if (lds > 160 * 1024) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: needs %zu B of LDS", lds);
+  const void* fn = R == 4 ? (const void*)rel_attention_kernel<4> : (const void*)rel_attention_kernel<8>;
+  static size_t configured[2] = {0, 0};
+  if (lds > 64 * 1024 && lds > configured[R == 4]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    configured = lds;
+    configured[R == 4] = 160 * 1024;
   }
   dim3 grid((unsigned)ceil_div(T, R), (unsigned)H, (unsigned)N);
-  hipLaunchKernelGGL(rel_attention_kernel, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
-                     out_batch_stride, G);
+  if (R == 4)
+    hipLaunchKernelGGL(rel_attention_kernel<4>, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
+                       out_batch_stride, G, TK);
+  else
+    hipLaunchKernelGGL(rel_attention_kernel<8>, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
+                       out_batch_stride, G, TK);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;

@@ -102,6 +102,14 @@ __device__ __forceinline__ void store_elem(const ConvArgs& p, int n, int row, in
   }
 }
 
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // Contraction steps fetched per prefetch group = G(K) channel pairs × K taps (≈ 7–11 steps)
 template <int K>
 struct GroupOf {
@@ -197,7 +205,11 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
             if (pos >= 0 && pos < p.Lin) okbits |= 1ull << (k * NT + nt);
           }
       }
-      float av[2][NA][S], bv[2][NX][S][NT];
+      // D groups form a register ring: D−1 groups of loads are in flight while one group feeds the matrix pipe.  With
+      // ~1–2 waves per SIMD (all a short utterance offers) this is what covers the 0.3–2 µs load latency.
+      constexpr int regs_per_group = S * (NA + NX * NT);
+      constexpr int D = BT > 256 ? 2 : (regs_per_group * 4 <= 112 ? 4 : (regs_per_group * 3 <= 132 ? 3 : 2));
+      float av[D][NA][S], bv[D][NX][S][NT];
       auto fetch = [&](auto slot_tag, const int g) {
         constexpr int sl = decltype(slot_tag)::value;
 #pragma unroll
@@ -227,8 +239,6 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
         constexpr int sl = decltype(slot_tag)::value;
 #pragma unroll
         for (int st = 0; st < S; st++) {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int k = st % K;
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
@@ -241,14 +251,19 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           }
         }
       };
-      using S0 = std::integral_constant<int, 0>;
-      using S1 = std::integral_constant<int, 1>;
-      if (g_begin < g_end) fetch(S0{}, g_begin);
-      for (int g = g_begin; g < g_end; g += 2) {
-        if (g + 1 < g_end) fetch(S1{}, g + 1);
-        compute(S0{});
-        if (g + 2 < g_end) fetch(S0{}, g + 2);
-        if (g + 1 < g_end) compute(S1{});
+      // The fetches are UNCONDITIONAL (past the slice end they re-fetch its last group, results unused): with a fetch
+      // under an `if`, hipcc has to pick the s_waitcnt vmcnt(N) that is safe on the path where the fetch did not happen,
+      // i.e. N ≈ 6 instead of ≈ 48 — which drains the whole ring before every group and serialises load and MFMA.
+      if (g_begin < g_end) {
+        const int g_last = g_end - 1;
+        static_for<D - 1>([&](auto d) { fetch(d, min(g_begin + d.value, g_last)); });
+        for (int g = g_begin; g < g_end; g += D) {
+          static_for<D>([&](auto d) {
+            const int gg = g + d.value;
+            fetch(std::integral_constant<int, (d.value + D - 1) % D>{}, min(gg + D - 1, g_last));
+            if (gg < g_end) compute(d);
+          });
+        }
       }
     };
     if (interior) body(std::false_type{});
@@ -370,6 +385,64 @@ __global__ __launch_bounds__(kBlock) void conv_direct_kernel(const ConvArgs p) {
       }
     }
     store_elem(p, n, co, xo, acc);
+  }
+}
+
+// Few output channels (HiFi-GAN conv_post: 32 → 1, k 7): HBM-bound, no matrix shape to speak of.  One output position
+// per thread; the (pre-activated, zero-padded) input window of the block goes through LDS once, so every input element
+// is read from memory exactly once and all of a thread's loads are independent (issued back to back).
+constexpr int kSmallCoutMax = 4, kSmallCK = 32, kSmallBT = 256;
+template <int PRO>
+__global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int halo = (p.K - 1) * (p.dil < 0 ? -p.dil : p.dil);
+  const int W = kSmallBT + halo;
+  float* xs = sm;                  // [kSmallCK][W]
+  float* ws = sm + kSmallCK * W;   // [Cout][kSmallCK][K]
+  const int n = blockIdx.y, t0 = blockIdx.x * kSmallBT, tid = threadIdx.x;
+  const int lo = t0 - p.padL + (p.dil < 0 ? (p.K - 1) * p.dil : 0);  // input position of window column 0
+  const float* xb = p.x + (int64_t)n * p.x_batch_stride;
+  const float* x2b = PRO == PRO_AVG3_LRELU ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
+  const float* x3b = PRO == PRO_AVG3_LRELU ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+  float acc[kSmallCoutMax];
+#pragma unroll
+  for (int co = 0; co < kSmallCoutMax; co++) acc[co] = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+  for (int c0 = 0; c0 < p.Cin; c0 += kSmallCK) {
+    const int ck = min(kSmallCK, p.Cin - c0);
+    __syncthreads();
+#pragma unroll 4
+    for (int idx = tid; idx < ck * W; idx += kSmallBT) {
+      const int c = idx / W, col = idx - c * W;
+      const int pos = lo + col;
+      const int64_t off = (int64_t)(p.in_ch_base + p.in_ch_sign * (c0 + c)) * p.Lin + pos;
+      const bool ok = pos >= 0 && pos < p.Lin;
+      float v = ok ? xb[off] : 0.0f;
+      if constexpr (PRO == PRO_AVG3_LRELU) v = ok ? ((v + x2b[off]) + x3b[off]) / 3.0f : 0.0f;
+      if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
+      xs[idx] = v;
+    }
+    for (int idx = tid; idx < p.Cout * ck * p.K; idx += kSmallBT) {
+      const int co = idx / (ck * p.K), rem = idx - co * ck * p.K;
+      const int c = rem / p.K, k = rem - c * p.K;
+      ws[(co * kSmallCK + c) * p.K + k] = p.w[((int64_t)co * p.Cin + c0 + c) * p.K + k];
+    }
+    __syncthreads();
+    const int colbase = tid - p.padL - (lo - t0);  // window column of tap 0 for this thread
+    for (int c = 0; c < ck; c++) {
+      const float* xr = xs + c * W + colbase;
+      for (int k = 0; k < p.K; k++) {
+        const float xv = xr[k * p.dil];
+#pragma unroll
+        for (int co = 0; co < kSmallCoutMax; co++)
+          if (co < p.Cout) acc[co] += xv * ws[(co * kSmallCK + c) * p.K + k];
+      }
+    }
+  }
+  const int xo = t0 + tid;
+  if (xo < p.Lout) {
+#pragma unroll
+    for (int co = 0; co < kSmallCoutMax; co++)
+      if (co < p.Cout) store_elem(p, n, co, xo, acc[co]);
   }
 }
 
@@ -504,8 +577,9 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   // tile shape: give every SIMD (4 per CU) a wave before growing the per-wave tile
   const int64_t want = (int64_t)ctx->num_cus * 4;
   int NT = 4;
+  // grow the per-wave tile only while every SIMD still gets ≥ 2 waves (a second wave is what hides load latency)
   auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, 32 * nt) * a.N; };
-  while (NT > 1 && waves(NT) < want) NT >>= 1;
+  while (NT > 1 && waves(NT) < 2 * want) NT >>= 1;
   if ((a.gate || a.prologue == PRO_AVG3_LRELU) && NT > 2) NT = 2;  // register budget: 2 accumulator sets / 3 raw inputs
   if (a.K >= 11 && NT > 2) NT = 2;
   // Split the contraction over KS waves of one block while SIMDs would otherwise idle and every slice keeps ≥ 2 prefetch
@@ -542,6 +616,19 @@ int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
   if (total <= 0) return PIPER_HIP_OK;
   if (a.epilogue == EPI_WN_RES_SKIP || a.epilogue == EPI_WN_SKIP_LAST || a.epilogue == EPI_CONVT || a.gate)
     PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "direct conv does not implement epilogue %d", a.epilogue);
+  const int halo = (a.K - 1) * (a.dil < 0 ? -a.dil : a.dil);
+  if (a.Cout <= kSmallCoutMax && a.stride == 1 && a.groups == 1 && a.N <= 65535 && halo <= 1024 && a.K <= 64) {
+    const dim3 g((unsigned)ceil_div(a.Lout, kSmallBT), (unsigned)a.N);
+    const size_t lds = ((size_t)kSmallCK * (kSmallBT + halo) + (size_t)a.Cout * kSmallCK * a.K) * sizeof(float);
+    switch (a.prologue) {
+      case PRO_NONE: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_NONE>, g, dim3(kSmallBT), lds, s, a); break;
+      case PRO_LRELU: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_LRELU>, g, dim3(kSmallBT), lds, s, a); break;
+      default: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_AVG3_LRELU>, g, dim3(kSmallBT), lds, s, a); break;
+    }
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_small_cout launch failed: %s", hipGetErrorString(e2));
+    return PIPER_HIP_OK;
+  }
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), (int64_t)ctx->num_cus * 16);
   switch (a.prologue) {
     case PRO_NONE: hipLaunchKernelGGL(conv_direct_kernel<PRO_NONE>, dim3(grid), dim3(kBlock), 0, s, a); break;
