@@ -17,6 +17,7 @@
 //
 // Replaces conv1d_f32 / convtranspose1d_f32 (Kernels/conv1d.metal:28-71, 97-142) and their encoders
 // (MetalBackend.swift:1149-1228, 2812-2895).
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv.h"
@@ -324,6 +325,178 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
   }
 }
 
+// ======================================================================================================
+// conv_tile_kernel — the bulk path (long rows: HiFi-GAN stages, long-form flow).
+//
+// PMC on the streaming kernel at L = 86 016 showed the matrix pipe ≈ 35 % busy with waves parked on VMEM: every MFMA was
+// pulling a fresh 512-byte B fragment through L1/L2 (K-fold re-reads of the activation row, ≈ 8 TB/s of cache traffic).
+// Here a 256-thread block owns BM = 32·MT output channels × BN = 128·NTW time steps; per chunk of CPC channel pairs it
+// stages the activation window [2·CPC][BN + halo] (pre-activation and zero padding applied on the way in) and the
+// matching weight fragments into LDS ONCE, and all K taps × MT row tiles × NTW time tiles are fed from LDS
+// (ds_read_b32, conflict-free: a wave reads 2 × 32 consecutive floats).  The next chunk's global loads are issued
+// before the current chunk's MFMAs and parked in registers, so HBM/L2 latency sits under the matrix work.
+// Global traffic per MFMA drops from ≈ 770 B to ≈ 80 B.
+template <int K, int MT, int NTW>
+struct TileCfg {
+  static constexpr int CPC = (128 / (MT * K)) >= 8 ? 8 : ((128 / (MT * K)) >= 4 ? 4 : ((128 / (MT * K)) >= 2 ? 2 : 1));
+  static constexpr int BN = 128 * NTW;
+  static constexpr int A_FLOATS = MT * CPC * K * 64;
+  static constexpr int A_PER_THREAD = A_FLOATS / 256;  // multiples of 256 by construction (64·MT·CPC·K)
+};
+
+template <int K, int MT, int NTW, int PRO>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const int nchunks_t, const int mgroups, const int nsteps,
+                                                        const int ldx, const int xs_floats) {
+  using Cfg = TileCfg<K, MT, NTW>;
+  constexpr int CPC = Cfg::CPC, BN = Cfg::BN;
+  constexpr int NX = (PRO == PRO_AVG3_LRELU) ? 3 : 1;
+  constexpr int XMAX = 24;  // staged activation elements per thread per chunk (host guarantees 2·CPC·W ≤ 256·XMAX)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xs = lds;               // [2·CPC][ldx]
+  float* As = lds + xs_floats;   // [MT][CPC·K][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int j = lane & 31, kk = lane >> 5;
+  const int chunk_t = blockIdx.x % nchunks_t, mg = blockIdx.x / nchunks_t;
+  const int n = blockIdx.y;
+  const int t0 = chunk_t * BN;
+  const int mt0 = mg * MT;
+  const int ncp = (p.Cin + 1) >> 1;
+  const int brow = p.ct_stride > 0 ? p.ct_stride : 1;
+  const int halo_lo = p.dil < 0 ? (K - 1) * p.dil : 0;  // ≤ 0
+  const int W = BN + (K - 1) * (p.dil < 0 ? -p.dil : p.dil);
+  const int lo = t0 - p.padL + halo_lo;  // input position of window column 0
+  const float* xb = p.x + (int64_t)n * p.x_batch_stride;
+  const float* x2b = NX == 3 ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
+  const float* x3b = NX == 3 ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+
+  f32x16 acc[MT][NTW];
+#pragma unroll
+  for (int m = 0; m < MT; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int row = (mt0 + m) * 32 + acc_row(r, lane);
+      const float b = (p.bias && row < p.Cout) ? p.bias[row / brow] : 0.0f;
+#pragma unroll
+      for (int nt = 0; nt < NTW; nt++) acc[m][nt][r] = b;
+    }
+
+  // staging registers.  The window is cut into 64-column segments; segment s = wave + 4·i of the [2·CPC][nseg] grid is
+  // slot i of this wave, so (row, segment) are wave-uniform scalars and the only per-lane address part is lane·4
+  // (no per-element integer division: the first version of this kernel spent more VALU time on e / W than on MFMAs).
+  float xr[NX][XMAX];
+  float ar[Cfg::A_PER_THREAD];
+  const int nseg = (W + 63) >> 6;
+  constexpr int nrows = 2 * CPC;
+  const int xbytes = (int)(p.x_batch_stride * 4);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, xbytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rx2 = rx, rx3 = rx;
+  if constexpr (NX == 3) {
+    rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)x2b, 0, xbytes, 0x00020000);
+    rx3 = __builtin_amdgcn_make_buffer_rsrc((void*)x3b, 0, xbytes, 0x00020000);
+  }
+  const int lane4 = lane * 4;
+  auto load_chunk = [&](const int c0 /*first channel pair*/) {
+    int row = 0, seg = wave;
+#pragma unroll
+    for (int i = 0; i < XMAX; i++) {
+      while (seg >= nseg) { seg -= nseg; row++; }
+      if (row < nrows) {
+        const int ch = 2 * c0 + row;
+        const int chc = ch < p.Cin ? ch : p.Cin - 1;
+        // element offset of (row, seg·64) in the tensor; negative / past-the-end offsets are range-checked to 0 by the
+        // descriptor, positions that fall into a neighbouring row are masked when the value is written to LDS
+        const int sbase = ((p.in_ch_base + p.in_ch_sign * chc) * p.Lin + lo + seg * 64) * 4;
+        xr[0][i] = bload(rx, sbase + lane4, 0);
+        if constexpr (NX == 3) {
+          xr[1][i] = bload(rx2, sbase + lane4, 0);
+          xr[2][i] = bload(rx3, sbase + lane4, 0);
+        }
+      }
+      seg += 4;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_THREAD; i++) {
+      const int e = tid + 256 * i;                 // [m][step in chunk][64]
+      const int m = e / (CPC * K * 64), r = e - m * (CPC * K * 64);
+      const int st = c0 * K + (r >> 6);            // global step of this tile row
+      const int mt = mt0 + m;
+      const bool ok = st < nsteps && mt * 32 < p.Cout;
+      ar[i] = ok ? p.w[((int64_t)mt * nsteps + st) * 64 + (r & 63)] : 0.0f;
+    }
+  };
+  auto store_chunk = [&](const int c0) {
+    int row = 0, seg = wave;
+#pragma unroll
+    for (int i = 0; i < XMAX; i++) {
+      while (seg >= nseg) { seg -= nseg; row++; }
+      if (row < nrows) {
+        const int col = seg * 64 + lane;
+        const int pos = lo + col;
+        const bool ok = (2 * c0 + row) < p.Cin && pos >= 0 && pos < p.Lin;
+        float v = xr[0][i];
+        if constexpr (NX == 3) v = ((v + xr[1][i]) + xr[2][i]) / 3.0f;
+        if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
+        if (col < W) Xs[row * ldx + col] = ok ? v : 0.0f;
+      }
+      seg += 4;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PER_THREAD; i++) As[tid + 256 * i] = ar[i];
+  };
+
+  const int colw = wave * (32 * NTW) - halo_lo + j;  // this lane's window column for tap 0, time tile 0
+  load_chunk(0);
+  for (int c0 = 0; c0 < ncp; c0 += CPC) {
+    __syncthreads();  // previous chunk fully consumed
+    store_chunk(c0);
+    __syncthreads();
+    if (c0 + CPC < ncp) load_chunk(c0 + CPC);  // in flight during the MFMAs below
+#pragma unroll
+    for (int cp = 0; cp < CPC; cp++) {
+      const float* xrow = Xs + (2 * cp + kk) * ldx + colw;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        float a[MT], b[NTW];
+#pragma unroll
+        for (int m = 0; m < MT; m++) a[m] = As[(m * CPC * K + cp * K + k) * 64 + lane];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) b[nt] = xrow[k * p.dil + 32 * nt];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+          for (int nt = 0; nt < NTW; nt++) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[nt], acc[m][nt], 0, 0, 0);
+      }
+    }
+  }
+
+  auto emit = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+      const int col = t0 + wave * (32 * NTW) + 32 * nt + j;
+      if (col >= p.Lout) continue;
+#pragma unroll
+      for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = (mt0 + m) * 32 + acc_row(r, lane);
+          if (row >= p.Cout) continue;
+          store_mode<MODE>(p, n, row, col, acc[m][nt][r]);
+        }
+    }
+  };
+  switch (p.epilogue) {  // wave-uniform
+    case EPI_STORE: emit(std::integral_constant<int, EPI_STORE>{}); break;
+    case EPI_RELU: emit(std::integral_constant<int, EPI_RELU>{}); break;
+    case EPI_TANH: emit(std::integral_constant<int, EPI_TANH>{}); break;
+    case EPI_RSUB: emit(std::integral_constant<int, EPI_RSUB>{}); break;
+    case EPI_WN_RES_SKIP: emit(std::integral_constant<int, EPI_WN_RES_SKIP>{}); break;
+    case EPI_WN_SKIP_LAST: emit(std::integral_constant<int, EPI_WN_SKIP_LAST>{}); break;
+    case EPI_CONVT: emit(std::integral_constant<int, EPI_CONVT>{}); break;
+  }
+}
+
 // ---- weight packing (once per voice; per call for the op-level API) ----
 __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
                                                            int K, int mtiles, int nsteps) {
@@ -529,6 +702,78 @@ bool launch_k(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int
   return false;
 }
 
+template <int K, int MT, int NTW, int PRO>
+bool launch_tile_one(hipStream_t s, const ConvArgs& a, int nsteps) {
+  using Cfg = TileCfg<K, MT, NTW>;
+  const int W = Cfg::BN + (K - 1) * (a.dil < 0 ? -a.dil : a.dil);
+  if (2 * Cfg::CPC * ((W + 63) / 64) > 4 * 24) return false;  // staging slots per wave (XMAX)
+  const int ldx = W + 1;
+  const int xs_floats = ((2 * Cfg::CPC * ldx + 63) / 64) * 64;
+  const size_t lds = (size_t)(xs_floats + Cfg::A_FLOATS) * sizeof(float);
+  if (lds > 160 * 1024) return false;
+  if (lds > 64 * 1024) {
+    static bool configured = false;
+    if (!configured) {
+      (void)hipFuncSetAttribute((const void*)conv_tile_kernel<K, MT, NTW, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      configured = true;
+    }
+  }
+  const int mtiles = (int)ceil_div(a.Cout, 32);
+  const int mgroups = (int)ceil_div(mtiles, MT);
+  const int nchunks_t = (int)ceil_div(a.Lout, Cfg::BN);
+  dim3 grid((unsigned)(nchunks_t * mgroups), (unsigned)a.N);
+  hipLaunchKernelGGL((conv_tile_kernel<K, MT, NTW, PRO>), grid, dim3(256), lds, s, a, nchunks_t, mgroups, nsteps, ldx, xs_floats);
+  return true;
+}
+
+template <int K, int PRO>
+bool launch_tile_shape(hipStream_t s, const ConvArgs& a, int MT, int NTW, int nsteps) {
+  if (MT == 1 && NTW == 2) return launch_tile_one<K, 1, 2, PRO>(s, a, nsteps);
+  if (MT == 2 && NTW == 2) return launch_tile_one<K, 2, 2, PRO>(s, a, nsteps);
+  if (MT == 4 && NTW == 1) return launch_tile_one<K, 4, 1, PRO>(s, a, nsteps);
+  if (MT == 2 && NTW == 1) return launch_tile_one<K, 2, 1, PRO>(s, a, nsteps);
+  if (MT == 1 && NTW == 1) return launch_tile_one<K, 1, 1, PRO>(s, a, nsteps);
+  return false;
+}
+
+template <int K>
+bool launch_tile_k(hipStream_t s, const ConvArgs& a, int MT, int NTW, int nsteps) {
+  switch (a.prologue) {
+    case PRO_NONE: return launch_tile_shape<K, PRO_NONE>(s, a, MT, NTW, nsteps);
+    case PRO_LRELU: return launch_tile_shape<K, PRO_LRELU>(s, a, MT, NTW, nsteps);
+    case PRO_AVG3_LRELU:
+      if constexpr (K == 2 || K == 1) return launch_tile_shape<K, PRO_AVG3_LRELU>(s, a, MT, NTW, nsteps);
+      return false;
+  }
+  return false;
+}
+
+// Bulk path eligibility + launch. Returns false when the streaming kernel should be used instead.
+bool try_launch_tile(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
+  static const int mode = [] { const char* e = getenv("PIPER_HIP_TILE"); return e ? atoi(e) : -1; }();  // A/B switch: 0 off, 1 force
+  if (mode == 0) return false;
+  if (a.gate || a.Lout < 2048) return false;
+  const int mtiles = (int)ceil_div(a.Cout, 32);
+  int MT = mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1);
+  int NTW = MT == 4 ? 1 : 2;
+  if (a.K >= 11 && MT == 4) MT = 2;  // keep the weight stage ≤ 32 KiB and CPC ≥ 2
+  // enough blocks to cover the chip?
+  const int64_t blocks = ceil_div(a.Lout, 128 * NTW) * ceil_div(mtiles, MT) * a.N;
+  // measured (factor 64): the tile kernel wins for ≤ 64 output channels on very long rows, the streaming kernel
+  // everywhere else (ConvTranspose phases, 128-channel stages, anything that gives < 4 blocks per CU)
+  if (mode != 1 && (blocks < 4 * ctx->num_cus || MT > 2 || a.epilogue == EPI_CONVT)) return false;
+  const int nsteps = padded_steps(a.Cin, a.K);
+  switch (a.K) {
+    case 1: return launch_tile_k<1>(s, a, MT, NTW, nsteps);
+    case 2: return launch_tile_k<2>(s, a, MT, NTW, nsteps);
+    case 3: return launch_tile_k<3>(s, a, MT, NTW, nsteps);
+    case 5: return launch_tile_k<5>(s, a, MT, NTW, nsteps);
+    case 7: return launch_tile_k<7>(s, a, MT, NTW, nsteps);
+    case 11: return launch_tile_k<11>(s, a, MT, NTW, nsteps);
+  }
+  return false;
+}
+
 }  // namespace
 
 size_t packed_conv_floats(int Cout, int Cin, int K) { return (size_t)ceil_div(Cout, 32) * (size_t)padded_steps(Cin, K) * 64; }
@@ -570,6 +815,11 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   if (!k_supported(a.K)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: no streaming kernel for %d taps", a.K);
   if (a.gate && (a.Cout % 64)) PH_FAIL(PIPER_HIP_ERR_SHAPE, "gated conv needs Cout %% 64 == 0 (got %d)", a.Cout);
   if (a.x_batch_stride * 4 > 0x7fffffffLL) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: input larger than 2 GiB per batch item");
+  if (try_launch_tile(ctx, s, a)) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_tile launch failed: %s", hipGetErrorString(e));
+    return PIPER_HIP_OK;
+  }
   const int mtiles = (int)ceil_div(a.Cout, 32);
   const int mt_eff = a.gate ? mtiles / 2 : mtiles;
   const int G = group_of(a.K);

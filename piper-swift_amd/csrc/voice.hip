@@ -13,6 +13,7 @@
 // (the reference re-decodes 401 initializers and re-uploads every Conv weight per synthesize: GraphExecutor.swift:187-189,
 // 1774-1780).  Utterances are independent, so a voice has several slots (stream + arena + graph) that overlap on the GPU.
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 
@@ -77,6 +78,8 @@ struct Step {
   std::string name;
   std::function<int(hipStream_t)> run;
   double flops = 0, bytes = 0;
+  int lane = 0;  // 0 = the slot's stream; 1, 2 = side streams between a FORK and a JOIN (independent ResBlocks of one stage)
+  enum Kind { LAUNCH, FORK, JOIN } kind = LAUNCH;
 };
 
 struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bias pointer into the resident blob
@@ -89,6 +92,8 @@ struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bi
 struct Slot {
   bool inited = false;
   hipStream_t stream = nullptr;
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int T = -1, F = -1;
   // device buffers
@@ -105,6 +110,7 @@ struct Slot {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool timed = false;
+  int cur_lane = 0;  // lane given to steps added by add_conv
   // host staging (pinned so the H2D copies are truly async)
   int64_t* h_ids = nullptr;
   int32_t* h_f2i = nullptr;
@@ -290,6 +296,11 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
     s.h_ids = nullptr; s.h_f2i = nullptr; s.h_cap_t = s.h_cap_f = 0;
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
+    if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
+    for (int i = 0; i < 2; i++) {
+      if (s.ev_join[i]) (void)hipEventDestroy(s.ev_join[i]);
+      if (s.side[i]) (void)hipStreamDestroy(s.side[i]);
+    }
     if (s.stream) (void)hipStreamDestroy(s.stream);
     s.inited = false;
   }
@@ -329,6 +340,7 @@ void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW&
   st.run = [ctx, a, mfma](hipStream_t q) { return mfma ? launch_conv_mfma(ctx, q, a) : launch_conv_direct(ctx, q, a); };
   st.flops = conv_flops(w.Cout, w.Cin, w.K, Lout_for_work);
   st.bytes = conv_bytes(w.Cin, a.gate ? w.Cout / 2 : w.Cout, w.K, Lout_for_work);
+  st.lane = s.cur_lane;
   s.steps.push_back(std::move(st));
 }
 
@@ -531,7 +543,14 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       st.bytes = 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
       s.steps.push_back(st);
     }
+    {  // the stage's ResBlocks read the same `up` and write disjoint buffers: run them as parallel graph branches
+      Step f;
+      f.name = p + "fork";
+      f.kind = Step::FORK;
+      s.steps.push_back(f);
+    }
     for (int j = 0; j < c.n_rb; j++) {
+      s.cur_lane = j < 3 ? j : 0;
       const int K = c.rb_kernels[j];
       const float* src = up;
       for (int di = 0; di < c.rb_n_dil; di++) {
@@ -553,6 +572,13 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
         src = dst;
       }
     }
+    s.cur_lane = 0;
+    {
+      Step jn;
+      jn.name = p + "join";
+      jn.kind = Step::JOIN;
+      s.steps.push_back(jn);
+    }
     cur[0] = r[0]; cur[1] = c.n_rb > 1 ? r[1] : nullptr; cur[2] = c.n_rb > 2 ? r[2] : nullptr;
     cur_is_mrf = true;
     L = Lo;
@@ -573,9 +599,25 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
   return PIPER_HIP_OK;
 }
 
-int run_schedule(Slot& s, hipStream_t q) {
+int run_schedule(Slot& s, hipStream_t q, bool parallel) {
   for (auto& st : s.steps) {
-    int rc = st.run(q);
+    if (st.kind == Step::FORK) {
+      if (parallel) {
+        PH_HIP(hipEventRecord(s.ev_fork, q), PIPER_HIP_ERR_LAUNCH);
+        for (int i = 0; i < 2; i++) PH_HIP(hipStreamWaitEvent(s.side[i], s.ev_fork, 0), PIPER_HIP_ERR_LAUNCH);
+      }
+      continue;
+    }
+    if (st.kind == Step::JOIN) {
+      if (parallel)
+        for (int i = 0; i < 2; i++) {
+          PH_HIP(hipEventRecord(s.ev_join[i], s.side[i]), PIPER_HIP_ERR_LAUNCH);
+          PH_HIP(hipStreamWaitEvent(q, s.ev_join[i], 0), PIPER_HIP_ERR_LAUNCH);
+        }
+      continue;
+    }
+    hipStream_t target = (parallel && st.lane > 0) ? s.side[st.lane - 1] : q;
+    int rc = st.run(target);
     if (rc) return rc;
   }
   hipError_t e = hipGetLastError();
@@ -588,6 +630,11 @@ int slot_init(piper_hip_voice* v, Slot& s) {
   PH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev0), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev1), PIPER_HIP_ERR_LAUNCH);
+  for (int i = 0; i < 2; i++) {
+    PH_HIP(hipStreamCreateWithFlags(&s.side[i], hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
+  }
+  PH_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
   s.inited = true;
   return PIPER_HIP_OK;
 }
@@ -720,14 +767,17 @@ PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_uttera
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // u->noise is caller memory
   if (rebuild) {
     // one eager pass validates every launch (and sets kernel attributes) before capture
-    if ((rc = run_schedule(s, s.stream))) { slot_release(v, s, false); return rc; }
+    if ((rc = run_schedule(s, s.stream, false))) { slot_release(v, s, false); return rc; }
     hipError_t e = hipStreamSynchronize(s.stream);
     if (e != hipSuccess) {
       slot_release(v, s, false);
       PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
     }
     PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
-    rc = run_schedule(s, s.stream);
+    // Parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three short kernels
+    // gain: factor 1 1.34 → 1.50 ms, factor 8 1.65 → 1.89 ms), so the graph stays a single chain unless asked otherwise.
+    static const bool par = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
+    rc = run_schedule(s, s.stream, par);
     hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
     if (rc || ce != hipSuccess) {
       slot_release(v, s, false);
@@ -825,7 +875,7 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
   for (int it = 0; it < iters + 1 && !rc; it++) {  // first pass is warm-up
     PH_HIP(hipEventRecord(ev[0], s.stream), PIPER_HIP_ERR_LAUNCH);
     for (int i = 0; i < n && !rc; i++) {
-      rc = s.steps[i].run(s.stream);
+      if (s.steps[i].kind == Step::LAUNCH) rc = s.steps[i].run(s.stream);
       if (!rc && hipEventRecord(ev[i + 1], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
     }
     if (rc) break;

@@ -289,3 +289,45 @@ def test_stream_semantics(backend):
     for _ in range(4):
         ref = np.tanh(orc.conv1d(ref, w, None, 1, 1, 1, 1, 1))
     assert_close(dl(b, cur, shp), ref, OP_TOL)
+
+
+# Long rows take the LDS-tiled bulk kernel (conv_tile_kernel); the KAT table above only reaches the streaming kernel.
+BULK_CONV = [  # (Cin, Cout, K, dil, L, lrelu)
+    (32, 32, 7, 12, 20000, True), (32, 32, 3, 1, 16384 + 5, True), (64, 64, 5, 6, 9000, True), (64, 64, 11, 5, 9000, True),
+    (128, 128, 7, 3, 6000, False), (256, 256, 3, 1, 4500, True), (32, 64, 1, 1, 20000, False), (48, 40, 5, 2, 20001, True),
+]
+
+
+@pytest.mark.parametrize("case", BULK_CONV, ids=[f"c{c[0]}x{c[1]}_k{c[2]}_d{c[3]}_L{c[4]}" for c in BULK_CONV])
+def test_conv1d_bulk(case, backend):
+    cin, cout, k, d, L, act = case
+    sd = 9000 + cin + 7 * k + d
+    x = kd.sym(sd, (1, cin, L))
+    w = kd.weight(sd + 1, (cout, cin, k), cin * k)
+    b = kd.sym(sd + 2, (cout,), 0.1)
+    pad = (k * d - d) // 2
+    bk = backend
+    if act:  # through the fused ResBlock entry point (LeakyReLU prologue + residual epilogue) when square
+        if cin == cout:
+            out = bk.hifiganResblockF32(2, up(bk, x), 1, cin, L, k, [d], [up(bk, w)], [up(bk, b)], 0.1)
+            ref = orc.hifigan_resblock(2, x, k, [d], [w], [b], 0.1)
+            assert_close(bk.downloadFloat32(out), ref, OP_TOL)
+            return
+        xa = bk.leakyReluF32(up(bk, x), x.size, 0.1)
+        x = orc.unary(ph.LEAKYRELU, x, 0.1)
+    else:
+        xa = up(bk, x)
+    out, shp = bk.conv1dF32(xa, list(x.shape), up(bk, w), list(w.shape), up(bk, b), dilation=d, padL=pad, padR=pad)
+    assert_close(dl(bk, out, shp), orc.conv1d(x, w, b, 1, d, pad, pad, 1), OP_TOL)
+
+
+@pytest.mark.parametrize("case", [(64, 32, 8, 4, 2, 6000), (128, 64, 16, 8, 4, 1500), (64, 32, 4, 2, 1, 9000)],
+                         ids=["k8s4", "k16s8", "k4s2"])
+def test_convtranspose1d_bulk(case, backend):
+    cin, cout, k, s, pad, L = case
+    x = kd.sym(7000 + k, (1, cin, L))
+    w = kd.weight(7001 + k, (cin, cout, k), cin * k // s)
+    b = kd.sym(7002 + k, (cout,), 0.1)
+    out, shp = backend.convTranspose1dF32(up(backend, x), list(x.shape), up(backend, w), list(w.shape), up(backend, b), stride=s,
+                                          padL=pad, padR=pad)
+    assert_close(dl(backend, out, shp), orc.convtranspose1d(x, w, b, s, 1, pad, pad, 0, 1), OP_TOL)
