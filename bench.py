@@ -19,6 +19,10 @@ import time
 
 import numpy as np
 
+# CPU share of a 1-GPU box is 16 cores; the oracle's OpenMP team must not oversubscribe the host
+_CORES = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+os.environ.setdefault("OMP_NUM_THREADS", str(_CORES))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "piper-swift_amd", "python"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,7 +84,8 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(wbuf, src=0)
+        from piper_hip import distributed as phd
+        phd.broadcast_blob(wbuf, src=0)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
         backend = ph.HipBackend(local_rank)
@@ -119,11 +124,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        import torch
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        from piper_hip import distributed as phd
+        elapsed = phd.max_over_ranks(elapsed, device="cuda")
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * args.steps * audio_sec / elapsed  # whole-job audio-seconds per wall-second
 
@@ -222,7 +224,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             import oracle as orc
             blob = ph.synthetic_blob(cfg, 1234)
-            cores = os.cpu_count() or 1
+            cores = int(os.environ.get("OMP_NUM_THREADS", _CORES))
             orc.synthesize(cfg, blob, FIXTURE_IDS, [3] * 14, None, 0.667)  # warm the library
             reps = 1
             a = time.perf_counter()

@@ -27,7 +27,8 @@ struct ConvArgs {
   const float* x = nullptr;   // [N, x_channels, Lin]
   const float* x2 = nullptr;  // PRO_AVG3_LRELU
   const float* x3 = nullptr;
-  const float* w = nullptr;   // MFMA path: packed fragments (pack_conv_weights); direct path: raw ONNX layout
+  const float* w = nullptr;   // MFMA path: packed 32-wide fragments (pack_conv_weights); direct path: raw ONNX layout
+  const float* w16 = nullptr; // optional packed 16-wide fragments (short-utterance geometry)
   const float* bias = nullptr;
   const float* res = nullptr;   // residual / minuend, same addressing as y
   const float* skip = nullptr;  // EPI_WN_*: running skip sum, same addressing as y2 (may be null)
@@ -53,11 +54,13 @@ struct ConvArgs {
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv
-size_t packed_conv_floats(int Cout, int Cin, int K);
+size_t packed_conv_floats(int Cout, int Cin, int K, int tm = 32);
 // ConvTranspose [Cin, Cout, K] stride s → rows Cout·s, taps ceil(K/s)
-size_t packed_convt_floats(int Cin, int Cout, int K, int s);
-int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
-int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed);
+size_t packed_convt_floats(int Cin, int Cout, int K, int s, int tm = 32);
+int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed, int tm = 32);
+int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed, int tm = 32);
+// tile geometry launch_conv_mfma will pick for this problem when 16-wide fragments are available (32 or 16)
+int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate);
 
 // true when the MFMA implicit-GEMM path can run this geometry
 bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups);

@@ -42,6 +42,21 @@ __device__ __forceinline__ float sigmoid_stable(float x) {  // elementwise.metal
 // accumulator register r of lane → tile row (guide §3 "Fragment layout")
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int TM> struct AccSel { using type = f32x16; };
+template <> struct AccSel<16> { using type = f32x4; };
+// 16x16x4: C/D col = lane & 15, row = 4·(lane >> 4) + reg; A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]
+template <int TM>
+__device__ __forceinline__ int acc_row_t(int r, int lane) {
+  if constexpr (TM == 32) return acc_row(r, lane);
+  else return 4 * (lane >> 4) + r;
+}
+template <int TM>
+__device__ __forceinline__ typename AccSel<TM>::type mfma_t(float a, float b, typename AccSel<TM>::type c) {
+  if constexpr (TM == 32) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 template <int PRO>
 __device__ __forceinline__ float load_b(const ConvArgs& p, const float* xrow, const float* x2row, const float* x3row, int pos,
                                         bool ch_ok) {
@@ -121,7 +136,11 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int s
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-// conv_stream_kernel<K taps, NT time tiles per wave, GATE, PRO, BT threads per block>
+// conv_stream_kernel<K taps, NT time tiles per wave, GATE, PRO, BT threads per block, TM tile edge>
+//
+// TM = 32: v_mfma_f32_32x32x2_f32 (2 channels per step); TM = 16: v_mfma_f32_16x16x4_f32 (4 channels per step).  The
+// 16-wide geometry exists for short utterances: a [192 × 112] output is 24 tiles of 32² but 84 of 16², and tiles ×
+// split-K slices is all the parallelism such a conv has.
 //
 // Everything that is the same for the 64 lanes of a wave — tile coordinates, contraction cursor, row bases, tap
 // offsets — is kept in SGPRs (the wave id goes through readfirstlane, otherwise hipcc treats all of it as per-lane
@@ -131,13 +150,16 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // buffer_load with an SGPR offset.  Zero padding inside a row is a per-lane bit mask computed once per tile and only
 // on tiles that touch a row edge.  Groups of G·K steps are double-buffered in registers (loads of group g+1 are in
 // flight while group g feeds the matrix pipe).
-template <int K, int NT, bool GATE, int PRO, int BT>
+template <int K, int NT, bool GATE, int PRO, int BT, int TM>
 __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const int nchunks, const int mtiles, const int ks_log2,
                                                          const int ngroups) {
   constexpr int G = GroupOf<K>::G, S = G * K;
+  constexpr int CPS = TM == 32 ? 2 : 4;   // input channels per contraction step
+  constexpr int NR = TM == 32 ? 16 : 4;   // accumulator registers per tile
+  using AccT = typename AccSel<TM>::type;
   constexpr int NA = GATE ? 2 : 1;
   constexpr int NX = (PRO == PRO_AVG3_LRELU) ? 3 : 1;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [KS-1][WT][NA][NT][16][64]
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [KS-1][WT][NA][NT][NR][64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int KS = 1 << ks_log2;
@@ -149,19 +171,19 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
   const bool active = tile < mt_eff * nchunks;
   const int mt = active ? tile % mt_eff : 0;
   const int chunk = active ? tile / mt_eff : 0;
-  const int t0 = chunk * 32 * NT;
-  const int j = lane & 31, kk = lane >> 5;
-  const int ncp = (p.Cin + 1) >> 1;
+  const int t0 = chunk * TM * NT;
+  const int j = lane & (TM - 1), kk = lane / TM;
+  const int ncp = (p.Cin + CPS - 1) / CPS;  // channel units (pairs / quads)
   const int nsteps = ngroups * S;  // packed steps per row tile (zero-padded to whole groups)
   const int brow = p.ct_stride > 0 ? p.ct_stride : 1;  // bias index = row / brow
 
-  f32x16 acc[NA][NT];
+  AccT acc[NA][NT];
 #pragma unroll
   for (int a = 0; a < NA; a++) {
-    const int mbase = (a == 0 ? mt : mt + mt_eff) * 32;
+    const int mbase = (a == 0 ? mt : mt + mt_eff) * TM;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int row = mbase + acc_row(r, lane);
+    for (int r = 0; r < NR; r++) {
+      const int row = mbase + acc_row_t<TM>(r, lane);
       const float b = (ks == 0 && p.bias && row < p.Cout) ? p.bias[row / brow] : 0.0f;
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) acc[a][nt][r] = b;
@@ -183,13 +205,13 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     if constexpr (GATE) rwb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)(mt + mt_eff) * nsteps * 64), 0, wbytes, 0x00020000);
     // lane parts of the addresses (bytes). Rows of a channel pair: {r0, r0+1}; with a reversed channel map the pair is
     // stored in descending order, so lane half kk picks row (1−kk) and r0 is lowered by one.
-    const int rowsel = p.in_ch_sign > 0 ? kk : 1 - kk;
+    const int rowsel = p.in_ch_sign > 0 ? kk : CPS - 1 - kk;
     const int voffB = (rowsel * p.Lin + j) * 4;
     const int voffA = lane * 4;
-    const int row_adj = p.in_ch_sign > 0 ? 0 : -1;
+    const int row_adj = p.in_ch_sign > 0 ? 0 : -(CPS - 1);
     const int tb = t0 - p.padL;
     // does any element of this tile's window fall outside [0, Lin)?  (wave-uniform)
-    const int span_lo = tb + (p.dil < 0 ? (K - 1) * p.dil : 0), span_hi = tb + (p.dil > 0 ? (K - 1) * p.dil : 0) + 32 * NT - 1;
+    const int span_lo = tb + (p.dil < 0 ? (K - 1) * p.dil : 0), span_hi = tb + (p.dil > 0 ? (K - 1) * p.dil : 0) + TM * NT - 1;
     const bool interior = span_lo >= 0 && span_hi < p.Lin;
 
     auto body = [&](auto edge_tag) {
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
         for (int k = 0; k < K; k++)
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
-            const int pos = tb + k * p.dil + 32 * nt + j;
+            const int pos = tb + k * p.dil + TM * nt + j;
             if (pos >= 0 && pos < p.Lin) okbits |= 1ull << (k * NT + nt);
           }
       }
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
         for (int gi = 0; gi < G; gi++) {
           const int cp = g * G + gi;
           const int cpc = cp < ncp ? cp : ncp - 1;  // padded steps carry zero weights; keep their rows legal
-          const int rowbase = (p.in_ch_base + p.in_ch_sign * 2 * cpc + row_adj) * p.Lin + tb;
+          const int rowbase = (p.in_ch_base + p.in_ch_sign * CPS * cpc + row_adj) * p.Lin + tb;
 #pragma unroll
           for (int k = 0; k < K; k++) {
             const int st = gi * K + k;
@@ -226,7 +248,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
             if constexpr (GATE) av[sl][1][st] = bload(rwb, voffA, soffA);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-              const int off = voffB + (rowbase + k * p.dil + 32 * nt) * 4;
+              const int off = voffB + (rowbase + k * p.dil + TM * nt) * 4;
               bv[sl][0][st][nt] = bload(rx, off, 0);
               if constexpr (NX == 3) {
                 bv[sl][1][st][nt] = bload(rx2, off, 0);
@@ -247,8 +269,8 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
             if constexpr (NX == 3) v = ((v + bv[sl][1][st][nt]) + bv[sl][2][st][nt]) / 3.0f;
             if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
             if constexpr (EDGE) v = ((okbits >> (k * NT + nt)) & 1ull) ? v : 0.0f;
-            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][0][st], v, acc[0][nt], 0, 0, 0);
-            if constexpr (GATE) acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sl][1][st], v, acc[1][nt], 0, 0, 0);
+            acc[0][nt] = mfma_t<TM>(av[sl][0][st], v, acc[0][nt]);
+            if constexpr (GATE) acc[1][nt] = mfma_t<TM>(av[sl][1][st], v, acc[1][nt]);
           }
         }
       };
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
   }
 
   if (KS > 1) {  // fixed-order reduction over the contraction slices: slice 0 + slice 1 + … (deterministic)
-    constexpr int per_wave = NA * NT * 16 * 64;
+    constexpr int per_wave = NA * NT * NR * 64;
     if (ks > 0) {
       float* dst = red + (int64_t)((ks - 1) * WT + tw) * per_wave + lane;
 #pragma unroll
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) dst[((a * NT + nt) * 16 + r) * 64] = acc[a][nt][r];
+          for (int r = 0; r < NR; r++) dst[((a * NT + nt) * NR + r) * 64] = acc[a][nt][r];
     }
     __syncthreads();
     if (ks == 0) {
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
 #pragma unroll
           for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][nt][r] += src[((a * NT + nt) * 16 + r) * 64];
+            for (int r = 0; r < NR; r++) acc[a][nt][r] += src[((a * NT + nt) * NR + r) * 64];
       }
     }
   }
@@ -302,11 +324,11 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-      const int col = t0 + 32 * nt + j;
+      const int col = t0 + TM * nt + j;
       if (col >= p.Lout) continue;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = mt * 32 + acc_row(r, lane);
+      for (int r = 0; r < NR; r++) {
+        const int row = mt * TM + acc_row_t<TM>(r, lane);
         if (row >= rows_out) continue;
         float v = acc[0][nt][r];
         if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
@@ -499,21 +521,23 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
 
 // ---- weight packing (once per voice; per call for the op-level API) ----
 __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
-                                                           int K, int mtiles, int nsteps) {
+                                                           int K, int mtiles, int nsteps, int tm) {
+  const int cps = tm == 32 ? 2 : 4;
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int lane = (int)(i & 63);
     const int64_t ms = i >> 6;
     const int step = (int)(ms % nsteps), mt = (int)(ms / nsteps);
     const int cp = step / K, tap = step - cp * K;  // steps beyond the real channel pairs are zero padding
-    const int co = mt * 32 + (lane & 31), ci = 2 * cp + (lane >> 5);
+    const int co = mt * tm + (lane & (tm - 1)), ci = cps * cp + lane / tm;
     out[i] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * K + tap] : 0.0f;
   }
 }
 
 // ConvTranspose [Cin, Cout, K], stride s → GEMM rows (co, phase), taps j: weight W[ci][co][phase + s·j]
 __global__ __launch_bounds__(kBlock) void pack_convt_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
-                                                            int K, int s, int J, int mtiles, int nsteps) {
+                                                            int K, int s, int J, int mtiles, int nsteps, int tm) {
+  const int cps = tm == 32 ? 2 : 4;
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   const int rows = Cout * s;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -521,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void pack_convt_kernel(const float* __restr
     const int64_t ms = i >> 6;
     const int step = (int)(ms % nsteps), mt = (int)(ms / nsteps);
     const int cp = step / J, jt = step - cp * J;
-    const int row = mt * 32 + (lane & 31), ci = 2 * cp + (lane >> 5);
+    const int row = mt * tm + (lane & (tm - 1)), ci = cps * cp + lane / tm;
     float v = 0.0f;
     if (row < rows && ci < Cin) {
       const int co = row / s, ph = row - co * s;
@@ -649,54 +673,57 @@ __global__ __launch_bounds__(kBlock) void convt_direct_kernel(const float* __res
 // tap counts with a compiled streaming kernel (Piper: 1, 3, 5, 7, 11; ConvTranspose phases: 2)
 inline bool k_supported(int K) { return K == 1 || K == 2 || K == 3 || K == 5 || K == 7 || K == 11; }
 inline int group_of(int K) { return K == 1 ? 8 : K == 2 ? 4 : K == 3 ? 3 : K == 5 ? 2 : 1; }
-inline int padded_steps(int Cin, int K) {
-  const int ncp = (Cin + 1) / 2, G = group_of(K);
-  return (int)ceil_div(ncp, G) * G * K;
+inline int padded_steps(int Cin, int K, int tm = 32) {
+  const int cps = tm == 32 ? 2 : 4;
+  const int ncu = (Cin + cps - 1) / cps, G = group_of(K);
+  return (int)ceil_div(ncu, G) * G * K;
 }
 
-template <int K, int NT, bool GATE, int PRO, int BT>
+template <int K, int NT, bool GATE, int PRO, int BT, int TM>
 void launch_one(hipStream_t s, const ConvArgs& a, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid, size_t lds) {
   if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS once per instantiation
     static bool configured = false;
     if (!configured) {
-      (void)hipFuncSetAttribute((const void*)conv_stream_kernel<K, NT, GATE, PRO, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)conv_stream_kernel<K, NT, GATE, PRO, BT, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
       configured = true;
     }
   }
-  hipLaunchKernelGGL((conv_stream_kernel<K, NT, GATE, PRO, BT>), grid, dim3(BT), lds, s, a, nchunks, mtiles, ks_log2, ngroups);
+  hipLaunchKernelGGL((conv_stream_kernel<K, NT, GATE, PRO, BT, TM>), grid, dim3(BT), lds, s, a, nchunks, mtiles, ks_log2, ngroups);
 }
 
-template <int K, bool GATE, int PRO>
+template <int K, bool GATE, int PRO, int TM>
 bool launch_shape(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid,
                   size_t lds) {
   if (BT == 256) {
-    if (NT == 1) { launch_one<K, 1, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
-    if (NT == 2) { launch_one<K, 2, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
-    if constexpr (!GATE && PRO != PRO_AVG3_LRELU)
-      if (NT == 4) { launch_one<K, 4, GATE, PRO, 256>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    if (NT == 1) { launch_one<K, 1, GATE, PRO, 256, TM>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    if constexpr (TM == 32) {
+      if (NT == 2) { launch_one<K, 2, GATE, PRO, 256, TM>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+      if constexpr (!GATE && PRO != PRO_AVG3_LRELU)
+        if (NT == 4) { launch_one<K, 4, GATE, PRO, 256, TM>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+    }
     return false;
   }
   if (NT != 1) return false;
-  if (BT == 512) { launch_one<K, 1, GATE, PRO, 512>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
-  if constexpr (!GATE)
-    if (BT == 1024) { launch_one<K, 1, GATE, PRO, 1024>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+  if (BT == 512) { launch_one<K, 1, GATE, PRO, 512, TM>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
+  if constexpr (!GATE || TM == 16)
+    if (BT == 1024) { launch_one<K, 1, GATE, PRO, 1024, TM>(s, a, nchunks, mtiles, ks_log2, ngroups, grid, lds); return true; }
   return false;
 }
 
-// which (K, GATE, PRO) combinations are compiled: every conv of the Piper graph + the op-level API's plain convs
-template <int K>
+// which (K, GATE, PRO, TM) combinations are compiled: every conv of the Piper graph + the op-level API's plain convs
+template <int K, int TM>
 bool launch_k(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid,
               size_t lds) {
   if (a.gate) {
     if (a.prologue != PRO_NONE) return false;
-    return launch_shape<K, true, PRO_NONE>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+    return launch_shape<K, true, PRO_NONE, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
   }
   switch (a.prologue) {
-    case PRO_NONE: return launch_shape<K, false, PRO_NONE>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
-    case PRO_LRELU: return launch_shape<K, false, PRO_LRELU>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+    case PRO_NONE: return launch_shape<K, false, PRO_NONE, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+    case PRO_LRELU: return launch_shape<K, false, PRO_LRELU, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
     case PRO_AVG3_LRELU:
-      if constexpr (K == 2 || K == 1) return launch_shape<K, false, PRO_AVG3_LRELU>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+      if constexpr (K == 2 || K == 1) return launch_shape<K, false, PRO_AVG3_LRELU, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
       return false;
   }
   return false;
@@ -776,28 +803,28 @@ bool try_launch_tile(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
 
 }  // namespace
 
-size_t packed_conv_floats(int Cout, int Cin, int K) { return (size_t)ceil_div(Cout, 32) * (size_t)padded_steps(Cin, K) * 64; }
-size_t packed_convt_floats(int Cin, int Cout, int K, int s) {
+size_t packed_conv_floats(int Cout, int Cin, int K, int tm) { return (size_t)ceil_div(Cout, tm) * (size_t)padded_steps(Cin, K, tm) * 64; }
+size_t packed_convt_floats(int Cin, int Cout, int K, int s, int tm) {
   const int J = (K + s - 1) / s;
-  return (size_t)ceil_div((int64_t)Cout * s, 32) * (size_t)padded_steps(Cin, J) * 64;
+  return (size_t)ceil_div((int64_t)Cout * s, tm) * (size_t)padded_steps(Cin, J, tm) * 64;
 }
 
-int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed) {
-  const int mtiles = (int)ceil_div(Cout, 32), nsteps = padded_steps(Cin, K);
+int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed, int tm) {
+  const int mtiles = (int)ceil_div(Cout, tm), nsteps = padded_steps(Cin, K, tm);
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps, tm);
   return PIPER_HIP_OK;
 }
 
-int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed) {
+int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed, int tm) {
   const int J = (K + stride - 1) / stride;
-  const int mtiles = (int)ceil_div((int64_t)Cout * stride, 32), nsteps = padded_steps(Cin, J);
+  const int mtiles = (int)ceil_div((int64_t)Cout * stride, tm), nsteps = padded_steps(Cin, J, tm);
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
-  hipLaunchKernelGGL(pack_convt_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cin, Cout, K, stride, J, mtiles, nsteps);
+  hipLaunchKernelGGL(pack_convt_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cin, Cout, K, stride, J, mtiles, nsteps, tm);
   return PIPER_HIP_OK;
 }
 
@@ -820,45 +847,72 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_tile launch failed: %s", hipGetErrorString(e));
     return PIPER_HIP_OK;
   }
-  const int mtiles = (int)ceil_div(a.Cout, 32);
+  // Tile geometry: 16×16 tiles when 32×32 tiles alone cannot give every CU one (short utterances) and the caller has
+  // the 16-wide fragment image.
+  int TM = 32;
+  {
+    const int64_t tiles32 = (a.gate ? ceil_div(a.Cout, 64) : ceil_div(a.Cout, 32)) * ceil_div(a.Lout, 32) * a.N;
+    if (a.w16 && tiles32 < ctx->num_cus && (!a.gate || a.Cout % 32 == 0)) TM = 16;
+  }
+  if (TM == 16) a.w = a.w16;
+  if (!a.w) PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: missing packed weights for %d-wide tiles", TM);
+  const int cps = TM == 32 ? 2 : 4;
+  const int mtiles = (int)ceil_div(a.Cout, TM);
   const int mt_eff = a.gate ? mtiles / 2 : mtiles;
   const int G = group_of(a.K);
-  const int ngroups = (int)ceil_div((a.Cin + 1) / 2, G);
+  const int ngroups = (int)ceil_div((a.Cin + cps - 1) / cps, G);
   // tile shape: give every SIMD (4 per CU) a wave before growing the per-wave tile
   const int64_t want = (int64_t)ctx->num_cus * 4;
-  int NT = 4;
+  int NT = TM == 32 ? 4 : 1;
   // grow the per-wave tile only while every SIMD still gets ≥ 2 waves (a second wave is what hides load latency)
-  auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, 32 * nt) * a.N; };
+  auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, TM * nt) * a.N; };
   while (NT > 1 && waves(NT) < 2 * want) NT >>= 1;
   if ((a.gate || a.prologue == PRO_AVG3_LRELU) && NT > 2) NT = 2;  // register budget: 2 accumulator sets / 3 raw inputs
   if (a.K >= 11 && NT > 2) NT = 2;
   // Split the contraction over KS waves of one block while SIMDs would otherwise idle and every slice keeps ≥ 2 prefetch
   // groups: short utterances have tiny outputs and long contractions, so this is their only parallelism.
   int ks_log2 = 0;
-  const int ks_cap = a.gate ? 3 : 4;  // the gated tile holds two accumulator sets: 512 threads keep it in 256 VGPRs
+  const int ks_cap = (a.gate && TM == 32) ? 3 : 4;  // the gated 32-wide tile holds two 16-register accumulator sets
   while (ks_log2 < ks_cap && waves(NT) * (1 << ks_log2) < want && ngroups / (2 << ks_log2) >= 2 && NT == 1) ks_log2++;
   const int KS = 1 << ks_log2;
   const int BT = KS <= 4 ? 256 : 64 * KS;
   const int WT = (BT / 64) / KS;
-  const int nchunks = (int)ceil_div(a.Lout, 32 * NT);
+  const int nchunks = (int)ceil_div(a.Lout, TM * NT);
   const int64_t tiles = (int64_t)mt_eff * nchunks;
   if (tiles > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: too many tiles");
   dim3 grid((unsigned)ceil_div(tiles, WT), (unsigned)a.N);
   const int NA = a.gate ? 2 : 1;
-  const size_t lds = KS > 1 ? (size_t)(KS - 1) * WT * NA * NT * 16 * 64 * sizeof(float) : 0;
+  const int NR = TM == 32 ? 16 : 4;
+  const size_t lds = KS > 1 ? (size_t)(KS - 1) * WT * NA * NT * NR * 64 * sizeof(float) : 0;
   bool ok = false;
-  switch (a.K) {
-    case 1: ok = launch_k<1>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
-    case 2: ok = launch_k<2>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
-    case 3: ok = launch_k<3>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
-    case 5: ok = launch_k<5>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
-    case 7: ok = launch_k<7>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
-    case 11: ok = launch_k<11>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+  if (TM == 32) {
+    switch (a.K) {
+      case 1: ok = launch_k<1, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 2: ok = launch_k<2, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 3: ok = launch_k<3, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 5: ok = launch_k<5, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 7: ok = launch_k<7, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 11: ok = launch_k<11, 32>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    }
+  } else {
+    switch (a.K) {
+      case 1: ok = launch_k<1, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 2: ok = launch_k<2, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 3: ok = launch_k<3, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 5: ok = launch_k<5, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 7: ok = launch_k<7, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+      case 11: ok = launch_k<11, 16>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds); break;
+    }
   }
-  if (!ok) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: variant K=%d NT=%d gate=%d prologue=%d not compiled", a.K, NT, a.gate, a.prologue);
+  if (!ok) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: variant K=%d NT=%d TM=%d gate=%d prologue=%d not compiled", a.K, NT, TM, a.gate, a.prologue);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_mfma launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;
+}
+
+int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate) {
+  const int64_t tiles32 = (gate ? ceil_div(Cout, 64) : ceil_div(Cout, 32)) * ceil_div(Lout, 32) * N;
+  return (tiles32 < ctx->num_cus && (!gate || Cout % 32 == 0)) ? 16 : 32;
 }
 
 int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {

@@ -51,12 +51,13 @@ PH_EXPORT int piper_hip_conv1d_f32(piper_hip_ctx* ctx, const float* x, const int
   a.Lin = (int)Lin; a.Lout = (int)Lout; a.stride = p->stride; a.groups = (int)g;
   a.x_batch_stride = Cin * Lin; a.y_batch_stride = Cout * Lout; a.y_len = (int)Lout;
   if (Lin >= 1 && conv_mfma_eligible((int)Cout, (int)Cin, (int)K, p->stride, (int)g)) {
+    const int tm = conv_pick_tile(ctx, (int)Cout, (int)Lout, (int)N, 0);
     float* packed = nullptr;
-    rc = pool_floats(ctx, packed_conv_floats((int)Cout, (int)Cin, (int)K), &packed);
+    rc = pool_floats(ctx, packed_conv_floats((int)Cout, (int)Cin, (int)K, tm), &packed);
     if (rc) return rc;
     defer_free(ctx, packed);
-    pack_conv_weights(ss.s, w, (int)Cout, (int)Cin, (int)K, packed);
-    a.w = packed;
+    pack_conv_weights(ss.s, w, (int)Cout, (int)Cin, (int)K, packed, tm);
+    if (tm == 16) a.w16 = packed; else a.w = packed;
     rc = launch_conv_mfma(ctx, ss.s, a);
   } else {
     a.w = w;
@@ -95,13 +96,16 @@ PH_EXPORT int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, 
   if (g == 1 && p->dilation == 1 && Cin >= 2 && Cout * s >= 8 && Lin >= 1) {
     // phase decomposition: output phase (x+padL) mod s is a dense conv with ceil(K/s) taps (no '%' test per tap)
     const int J = (int)((K + s - 1) / s);
+    const int Lg = (int)((Lout - 1 + p->pad_l) / s + 1);
+    const int tm = conv_pick_tile(ctx, (int)(Cout * s), Lg, (int)N, 0);
     float* packed = nullptr;
-    rc = pool_floats(ctx, packed_convt_floats((int)Cin, (int)Cout, (int)K, s), &packed);
+    rc = pool_floats(ctx, packed_convt_floats((int)Cin, (int)Cout, (int)K, s, tm), &packed);
     if (rc) return rc;
     defer_free(ctx, packed);
-    pack_convt_weights(ss.s, w, (int)Cin, (int)Cout, (int)K, s, packed);
+    pack_convt_weights(ss.s, w, (int)Cin, (int)Cout, (int)K, s, packed, tm);
     ConvArgs a;
-    a.x = x; a.w = packed; a.bias = bias; a.y = *out;
+    a.x = x; a.bias = bias; a.y = *out;
+    if (tm == 16) a.w16 = packed; else a.w = packed;
     a.N = (int)N; a.Cin = (int)Cin; a.Cout = (int)(Cout * s); a.K = J; a.dil = -1; a.padL = 0;
     a.Lin = (int)Lin; a.Lout = (int)((Lout - 1 + p->pad_l) / s + 1);
     a.x_batch_stride = Cin * Lin; a.y_batch_stride = Cout * Lout; a.y_len = (int)Lout;
@@ -138,21 +142,24 @@ PH_EXPORT int piper_hip_wavenet_layer_f32(piper_hip_ctx* ctx, const float* x, co
   const int C = (int)c, T = (int)t, K = (int)k;
   const int Crs = last ? C : 2 * C;
   float *p_in = nullptr, *p_rs = nullptr, *acts = nullptr;
-  if ((rc = pool_floats(ctx, packed_conv_floats(2 * C, C, K), &p_in))) return rc;
+  const int tm_in = conv_pick_tile(ctx, 2 * C, T, (int)n, 1), tm_rs = conv_pick_tile(ctx, Crs, T, (int)n, 0);
+  if ((rc = pool_floats(ctx, packed_conv_floats(2 * C, C, K, tm_in), &p_in))) return rc;
   defer_free(ctx, p_in);
-  if ((rc = pool_floats(ctx, packed_conv_floats(Crs, C, 1), &p_rs))) return rc;
+  if ((rc = pool_floats(ctx, packed_conv_floats(Crs, C, 1, tm_rs), &p_rs))) return rc;
   defer_free(ctx, p_rs);
   if ((rc = pool_floats(ctx, cnt, &acts))) return rc;
   defer_free(ctx, acts);
-  pack_conv_weights(ss.s, w_in, 2 * C, C, K, p_in);
-  pack_conv_weights(ss.s, w_rs, Crs, C, 1, p_rs);
+  pack_conv_weights(ss.s, w_in, 2 * C, C, K, p_in, tm_in);
+  pack_conv_weights(ss.s, w_rs, Crs, C, 1, p_rs, tm_rs);
   ConvArgs a;  // in_conv + tanh·sigmoid gate
-  a.x = x; a.w = p_in; a.bias = b_in; a.y = acts;
+  a.x = x; a.bias = b_in; a.y = acts;
+  if (tm_in == 16) a.w16 = p_in; else a.w = p_in;
   a.N = (int)n; a.Cin = C; a.Cout = 2 * C; a.K = K; a.dil = (int)dilation; a.padL = (int)((k * dilation - dilation) / 2);
   a.Lin = T; a.Lout = T; a.x_batch_stride = (int64_t)C * T; a.y_batch_stride = (int64_t)C * T; a.y_len = T; a.gate = 1;
   if ((rc = launch_conv_mfma(ctx, ss.s, a))) return rc;
   ConvArgs b;  // res/skip 1×1 conv routed into x and skip
-  b.x = acts; b.w = p_rs; b.bias = b_rs;
+  b.x = acts; b.bias = b_rs;
+  if (tm_rs == 16) b.w16 = p_rs; else b.w = p_rs;
   b.N = (int)n; b.Cin = C; b.Cout = Crs; b.K = 1; b.Lin = T; b.Lout = T;
   b.x_batch_stride = (int64_t)C * T; b.y_batch_stride = (int64_t)C * T; b.y2_batch_stride = (int64_t)C * T; b.y_len = T;
   b.skip = skip_in; b.y2 = *skip_out;
@@ -199,12 +206,13 @@ PH_EXPORT int piper_hip_hifigan_resblock_f32(piper_hip_ctx* ctx, int type, const
     a.x_batch_stride = (int64_t)C * T; a.y_batch_stride = (int64_t)C * T; a.y_len = T;
     a.prologue = PRO_LRELU; a.alpha = lrelu_slope;
     if (mfma) {
+      const int tm = conv_pick_tile(ctx, C, T, (int)n, 0);
       float* packed = nullptr;
-      int r = pool_floats(ctx, packed_conv_floats(C, C, K), &packed);
+      int r = pool_floats(ctx, packed_conv_floats(C, C, K, tm), &packed);
       if (r) return r;
       defer_free(ctx, packed);
-      pack_conv_weights(ss.s, w, C, C, K, packed);
-      a.w = packed;
+      pack_conv_weights(ss.s, w, C, C, K, packed, tm);
+      if (tm == 16) a.w16 = packed; else a.w = packed;
       return launch_conv_mfma(ctx, ss.s, a);
     }
     a.w = w;

@@ -1,0 +1,72 @@
+"""CPU, world_size 2 over gloo: the N>1 path's host logic — one-shot weight broadcast and utterance sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import piper_hip as ph
+from piper_hip import distributed as phd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = ph.voice_config("medium")
+        n = ph.blob_floats(cfg)
+        if rank == 0:
+            blob = torch.from_numpy(ph.synthetic_blob(cfg, 1234))
+        else:
+            blob = torch.zeros(n, dtype=torch.float32)
+        phd.broadcast_blob(blob, src=0)
+        # every rank ends up with rank 0's bytes
+        digest = float(blob.double().sum()) + float(blob[::4097].double().abs().sum())
+        # disjoint shards of the batch-32 config, no data-path collective
+        factors = phd.batch32_factors()
+        shards = phd.shard_utterances([14 * f for f in factors], world)
+        mine = shards[rank]
+        audio_sec = sum(14 * factors[i] * 3 * 256 / 22050.0 for i in mine)
+        total = phd.sum_over_ranks(audio_sec)
+        slowest = phd.max_over_ranks(0.001 * (rank + 1))
+        ret[rank] = dict(digest=digest, mine=mine, total=total, slowest=slowest)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        r0, r1 = ret[0], ret[1]
+    assert r0["digest"] == r1["digest"] != 0.0
+    assert sorted(r0["mine"] + r1["mine"]) == list(range(32))
+    assert not set(r0["mine"]) & set(r1["mine"])
+    assert abs(r0["total"] - 101.4) < 0.1 and r0["total"] == r1["total"]  # 101.4 s of audio in the batch
+    assert r0["slowest"] == r1["slowest"] == 0.002
+
+
+def test_lpt_partition_balance():
+    factors = phd.batch32_factors()
+    assert sorted(factors) == sorted([1, 2, 3, 4, 6, 8, 12, 16] * 4) and factors != sorted(factors)
+    assert sum(14 * f for f in factors) == 2912  # ids in the batch
+    for world in (1, 2, 4, 8):
+        shards = phd.shard_utterances([14 * f for f in factors], world)
+        loads = [sum(14 * factors[i] for i in sh) for sh in shards]
+        assert sum(loads) == 2912 and max(loads) - min(loads) <= 14 * 16
+        assert sorted(i for sh in shards for i in sh) == list(range(32))
+    # 8 GPUs: every rank gets 364 ids (one utterance of each factor group)
+    assert set(sum(14 * factors[i] for i in sh) for sh in phd.shard_utterances([14 * f for f in factors], 8)) == {364}
