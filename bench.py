@@ -158,7 +158,7 @@ def main():
         if not args.no_profile:
             stats = rt.profile(0, iters=10)
             conv = [s for s in stats if s["flops"] > 0 and "rel_attention" not in s["name"] and s["name"] != "expand_noise"]
-            mfma = [s for s in conv if "conv_post" not in s["name"]]
+            mfma = [s for s in conv if "conv_post" not in s["name"]]  # conv_post is the HBM-bound small-Cout kernel
             tot_us = sum(s["avg_us"] for s in stats)
             m_us, m_fl, m_by = sum(s["avg_us"] for s in mfma), sum(s["flops"] for s in mfma), sum(s["bytes"] for s in mfma)
             achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   float* part = qe + R * W;       // [G][R][d]
   float* kv = part + G * R * d;   // [d][TK+1]
   float* sc = kv + d * ld;        // [R][T]
+  float* eks = sc + R * T;        // [W][d] relative-key embeddings
+  float* evs = eks + W * d;       // [W][d] relative-value embeddings
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * R, h = blockIdx.y, n = blockIdx.z;
   const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
@@ -52,6 +54,11 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   const float* vb = v + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
   const float scale = sqrtf((float)d);
 
+  // 0. the two small embedding tables go to LDS with the q strip (one memory round trip for all three)
+  for (int idx = tid; idx < W * d; idx += kBlock) {
+    eks[idx] = ek[idx];
+    evs[idx] = ev[idx];
+  }
   // 1. q strip, scaled by Div like the graph (query / sqrt(k_channels))
   for (int idx = tid; idx < R * d; idx += kBlock) {
     const int c = idx / R, r = idx - c * R;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     const int r = idx / W, m = idx - r * W;
     float s = 0.0f;
 #pragma unroll 8
-    for (int c = 0; c < d; c++) s += qs[r * d + c] * ek[m * d + c];
+    for (int c = 0; c < d; c++) s += qs[r * d + c] * eks[m * d + c];
     qe[r * W + m] = s;
   }
   // 2. score strip, one key tile at a time
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     float rel = 0.0f;
     for (int m = 0; m < W; m++) {
       const int j = i + m - w;
-      if (j >= 0 && j < T) rel = fmaf(sc[r * T + j], ev[m * d + c], rel);
+      if (j >= 0 && j < T) rel = fmaf(sc[r * T + j], evs[m * d + c], rel);
     }
     ob[(int64_t)c * T + i] = o + rel;
   }
@@ -178,7 +185,7 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   // query rows per block: fewer rows → more blocks (short utterances have only T/R·H of them); 4 rows also keeps the score
   // strip of the longest utterances inside the 160 KiB of LDS
   const int R = (T > 2048 || (int64_t)ceil_div(T, 8) * H * N < ctx->num_cus) ? 4 : 8;
-  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T) * sizeof(float);
+  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T + 2 * (2 * w + 1) * d) * sizeof(float);
   if (lds > 160 * 1024) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: needs %zu B of LDS", lds);
   const void* fn = R == 4 ? (const void*)rel_attention_kernel<4> : (const void*)rel_attention_kernel<8>;
   static size_t configured[2] = {0, 0};

@@ -270,14 +270,19 @@ __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __re
   const bool ok = t < T;
   const float* xb = x + n * (int64_t)C * T;
   const float* yb = y ? y + n * (int64_t)C * T : nullptr;
-  float v[kLnMaxV], w[kLnMaxV];
+  float v[kLnMaxV], w[kLnMaxV], ga[kLnMaxV], be[kLnMaxV];
 #pragma unroll
   for (int i = 0; i < kLnMaxV; i++) {
-    const int c = g + kLnG * i;
-    const bool in = ok && c < C;
-    const int64_t idx = in ? (int64_t)c * T + t : 0;
-    v[i] = xb[idx];
-    w[i] = yb ? yb[idx] : 0.0f;
+    v[i] = 0.0f; w[i] = 0.0f; ga[i] = 0.0f; be[i] = 0.0f;
+    if (kLnG * i < C) {  // block-uniform: rows of 16 channels that do not exist issue no loads at all
+      const int c = g + kLnG * i;
+      const bool in = ok && c < C;
+      const int64_t idx = in ? (int64_t)c * T + t : 0;
+      v[i] = xb[idx];
+      if (yb) w[i] = yb[idx];
+      ga[i] = gamma[c < C ? c : 0];  // fetched with x/y so the normalise step needs no second memory round trip
+      be[i] = beta[c < C ? c : 0];
+    }
   }
   float s = 0.0f;
 #pragma unroll
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < kLnMaxV; i++) {
       const int c = g + kLnG * i;
-      if (c < C) out[n * (int64_t)C * T + (int64_t)c * T + t] = (v[i] / sd) * gamma[c] + beta[c];
+      if (c < C) out[n * (int64_t)C * T + (int64_t)c * T + t] = (v[i] / sd) * ga[i] + be[i];
     }
   }
 }

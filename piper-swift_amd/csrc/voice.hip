@@ -66,6 +66,30 @@ __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __res
   }
 }
 
+// HiFi-GAN multi-receptive-field mean + the LeakyReLU that follows it: y = lrelu(((a + b) + c) / 3, alpha).
+// Done once per element here instead of inside the consumer conv, which re-reads every input element
+// (row tiles × taps) times — the in-conv form paid 3 loads and one IEEE division per re-read.
+__global__ __launch_bounds__(kBlock) void mrf_mean_lrelu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                const float* __restrict__ c, float* __restrict__ y, int64_t n,
+                                                                float alpha) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+    const float4 va = reinterpret_cast<const float4*>(a)[i], vb = reinterpret_cast<const float4*>(b)[i],
+                 vc = reinterpret_cast<const float4*>(c)[i];
+    float4 r;
+    r.x = ((va.x + vb.x) + vc.x) / 3.0f; r.y = ((va.y + vb.y) + vc.y) / 3.0f;
+    r.z = ((va.z + vb.z) + vc.z) / 3.0f; r.w = ((va.w + vb.w) + vc.w) / 3.0f;
+    r.x = r.x >= 0.0f ? r.x : alpha * r.x; r.y = r.y >= 0.0f ? r.y : alpha * r.y;
+    r.z = r.z >= 0.0f ? r.z : alpha * r.z; r.w = r.w >= 0.0f ? r.w : alpha * r.w;
+    reinterpret_cast<float4*>(y)[i] = r;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const float v = ((a[i] + b[i]) + c[i]) / 3.0f;
+    y[i] = v >= 0.0f ? v : alpha * v;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void flip_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L) {
   const int64_t total = (int64_t)C * L;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -368,6 +392,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
   slot_release(v, s, false);
   Arena ar{v, &s};
+  if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F;
   s.ids = (int64_t*)ar.raw((size_t)T * sizeof(int64_t));
   s.frame2id = (int32_t*)ar.raw((size_t)F * sizeof(int32_t));
@@ -547,8 +572,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     const std::string p = "dec.s" + std::to_string(u) + ".";
     {
       ConvArgs a;
-      a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
-      a.prologue = cur_is_mrf ? PRO_AVG3_LRELU : PRO_LRELU;
+      a.x = cur[0];
+      a.prologue = cur_is_mrf ? PRO_NONE : PRO_LRELU;  // the MRF mean kernel already applied LeakyReLU(0.1)
       a.alpha = 0.1f;
       a.y = up; a.N = 1; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
       a.x_batch_stride = (int64_t)S.Cin * L; a.y_batch_stride = (int64_t)S.Cout * Lo; a.y_len = Lo;
@@ -597,22 +622,36 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       jn.kind = Step::JOIN;
       s.steps.push_back(jn);
     }
-    cur[0] = r[0]; cur[1] = c.n_rb > 1 ? r[1] : nullptr; cur[2] = c.n_rb > 2 ? r[2] : nullptr;
+    {
+      float* m = ar.f32((size_t)S.Cout * Lo);
+      if (ar.rc) return ar.rc;
+      Step st;
+      st.name = p + "mrf_mean_lrelu";
+      const float *r0 = r[0], *r1 = r[1], *r2 = r[2];
+      const int64_t cnt = (int64_t)S.Cout * Lo;
+      const float alpha = (u + 1 == c.n_ups) ? 0.01f : 0.1f;  // F.leaky_relu default slope before conv_post
+      st.run = [=](hipStream_t q) {
+        const int grid = (int)std::min<int64_t>(ceil_div(cnt, (int64_t)kBlock * 4), 2048);
+        hipLaunchKernelGGL(mrf_mean_lrelu_kernel, dim3(grid), dim3(kBlock), 0, q, r0, r1, r2, m, cnt, alpha);
+        return PIPER_HIP_OK;
+      };
+      s.steps.push_back(st);
+      cur[0] = m; cur[1] = nullptr; cur[2] = nullptr;
+    }
     cur_is_mrf = true;
     L = Lo;
   }
-  if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.n_samples = L;
   s.audio = ar.f32((size_t)L);
   if (ar.rc) return ar.rc;
   {
     ConvArgs a;
-    a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
-    a.prologue = PRO_AVG3_LRELU; a.alpha = 0.01f;
+    a.x = cur[0];
+    a.prologue = PRO_NONE;  // LeakyReLU(0.01) of the MRF mean was applied by the mean kernel
     a.y = s.audio; a.N = 1; a.padL = 3; a.Lin = L; a.Lout = L;
     a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
     a.epilogue = EPI_TANH;
-    add_conv(v, s, "dec.mrf_lrelu_conv_post_tanh", v->conv_post, a, L);
+    add_conv(v, s, "dec.conv_post_tanh", v->conv_post, a, L);
   }
   return PIPER_HIP_OK;
 }
