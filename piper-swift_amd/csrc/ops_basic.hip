@@ -259,7 +259,10 @@ __global__ __launch_bounds__(kBlock) void softmax_block_kernel(const float* __re
 // x,y [N,C,T]; normalise over C for each (n,t). Block = 16 time steps × 16 channel lanes.  Every thread first issues ALL
 // of its loads (≤ 2·kLnMaxV independent requests in flight), keeps x+y in registers, and the two reductions go through
 // LDS — one memory round trip instead of three dependent passes (at T≈100 the op is pure latency, not bandwidth).
-constexpr int kLnT = 16, kLnG = 16, kLnMaxV = 32;  // C ≤ kLnG·kLnMaxV = 512
+constexpr int kLnT = 16, kLnG = 16;
+// kLnMaxV = register slots per thread (C ≤ 16·kLnMaxV).  Instantiated at 12 (C ≤ 192, every Piper voice) and 32: the
+// unrolled body is straight-line code fetched cold on every launch, so the small instance is ~2.5× less I-cache traffic.
+template <int kLnMaxV>
 __global__ __launch_bounds__(kBlock) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ out, int C, int T, float eps) {
@@ -745,8 +748,10 @@ PH_EXPORT int piper_hip_add_layernorm_f32(piper_hip_ctx* ctx, const float* x, co
   ph::StreamScope ss(ctx, stream);
   if (c * t > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "add_layernorm: tensor too large");
   const dim3 grid((unsigned)ph::ceil_div(t, kLnT), (unsigned)n);
-  if (c <= kLnG * kLnMaxV)
-    hipLaunchKernelGGL(add_layernorm_kernel, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
+  if (c <= kLnG * 12)
+    hipLaunchKernelGGL(add_layernorm_kernel<12>, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
+  else if (c <= kLnG * 32)
+    hipLaunchKernelGGL(add_layernorm_kernel<32>, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
   else
     hipLaunchKernelGGL(add_layernorm_big_kernel, grid, dim3(kBlock), 0, ss.s, x, y, gamma, beta, *out, (int)c, (int)t, eps);
   return ss.finish("add_layernorm_f32");

@@ -100,6 +100,8 @@ __global__ __launch_bounds__(kBlock) void flip_channels_kernel(const float* __re
 
 // keeps the GPU busy for `ticks` of the 100 MHz realtime counter: lets the host queue a whole profiled pass ahead of the
 // GPU, so the per-launch event deltas contain the ~1.7 µs kernel boundary but not host launch latency
+__global__ void empty_kernel() {}
+
 __global__ void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
@@ -109,6 +111,7 @@ struct Step {
   std::string name;
   std::function<int(hipStream_t)> run;
   double flops = 0, bytes = 0;
+  std::string tag;  // kernel family ("conv_mfma", "conv_small", "rel_attention", …) for piper_hip_voice_time_subset
   int lane = 0;  // 0 = the slot's stream; 1, 2 = side streams between a FORK and a JOIN (independent ResBlocks of one stage)
   enum Kind { LAUNCH, FORK, JOIN } kind = LAUNCH;
 };
@@ -383,6 +386,7 @@ void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW&
   st.flops = conv_flops(w.Cout, w.Cin, w.K, Lout_for_work);
   st.bytes = conv_bytes(w.Cin, a.gate ? w.Cout / 2 : w.Cout, w.K, Lout_for_work);
   st.lane = s.cur_lane;
+  st.tag = mfma ? "conv_mfma" : "conv_small";
   s.steps.push_back(std::move(st));
 }
 
@@ -442,6 +446,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     {
       Step st;
       st.name = p + "rel_attention";
+      st.tag = "rel_attention";
       const float *ek = L.ek, *ev = L.ev;
       const int nh = c.n_heads, w = c.window;
       st.run = [=](hipStream_t q) {
@@ -457,6 +462,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     auto add_ln = [&](const std::string& nm, const float* a, const float* b, const float* g, const float* be, float* out) {
       Step st;
       st.name = nm;
+      st.tag = "add_layernorm";
       st.run = [=](hipStream_t q) {
         float* o = out;
         return piper_hip_add_layernorm_f32(ctx, a, b, g, be, 1, H, T, 1e-5f, &o, (piper_hip_stream)q);
@@ -581,6 +587,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       a.w = S.up.w; a.w16 = S.up.w16; a.bias = S.up.bias; a.Cin = S.up.Cin; a.Cout = S.up.Cout; a.K = S.up.K;
       Step st;
       st.name = p + "lrelu_convT";
+      st.tag = "conv_mfma";
       st.run = [ctx, a](hipStream_t q) { return launch_conv_mfma(ctx, q, a); };
       st.flops = 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
       st.bytes = 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
@@ -945,6 +952,22 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
       acc[i] += ms * 1000.0;
     }
   }
+  // event floor: the same bracket around an empty kernel (dispatch boundary + event markers, no work) — what has to be
+  // subtracted from a step's event delta to compare it with rocprofv3's begin→end kernel duration
+  double floor_us = 0.0;
+  if (!rc) {
+    const int nf = std::min(32, n);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s.stream, (unsigned long long)(100 * 800));
+    if (hipEventRecord(ev[0], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
+    for (int i = 1; i <= nf && !rc; i++) {
+      hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s.stream);
+      if (hipEventRecord(ev[i], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
+    }
+    if (!rc && nf > 0 && hipStreamSynchronize(s.stream) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev[0], ev[nf]) == hipSuccess) floor_us = ms * 1000.0 / nf;
+    }
+  }
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (rc) return rc;
   for (int i = 0; i < n && i < max_entries; i++) {
@@ -954,5 +977,66 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
     out[i].flops = s.steps[i].flops;
     out[i].bytes = s.steps[i].bytes;
   }
+  if (n < max_entries) {  // extra pseudo-entry carrying the calibration
+    memset(&out[n], 0, sizeof out[n]);
+    snprintf(out[n].name, sizeof out[n].name, "(event floor: empty kernel)");
+    out[n].avg_us = floor_us;
+    if (n_entries) *n_entries = n + 1;
+  }
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const char* name_filter, int iters, double* avg_launch_us,
+                                          int* n_launches, double* flops, double* bytes) {
+  if (!v || !name_filter) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  if (iters < 1) iters = 1;
+  Slot& s = v->slots[slot];
+  std::vector<int> pick;
+  double fl = 0, by = 0;
+  for (int i = 0; i < (int)s.steps.size(); i++)
+    if (s.steps[i].kind == Step::LAUNCH &&
+        (s.steps[i].name.find(name_filter) != std::string::npos || (!s.steps[i].tag.empty() && s.steps[i].tag == name_filter))) {
+      pick.push_back(i);
+      fl += s.steps[i].flops;
+      by += s.steps[i].bytes;
+    }
+  if (n_launches) *n_launches = (int)pick.size();
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  if (pick.empty()) {
+    if (avg_launch_us) *avg_launch_us = 0;
+    return PIPER_HIP_OK;
+  }
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
+  int rc = PIPER_HIP_OK;
+  for (int i : pick)
+    if ((rc = s.steps[i].run(s.stream))) break;
+  hipError_t ce = hipStreamEndCapture(s.stream, &g);
+  if (rc || ce != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    if (rc) return rc;
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "time_subset: capture failed: %s", hipGetErrorString(ce));
+  }
+  ce = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  if (ce != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "time_subset: instantiate failed: %s", hipGetErrorString(ce));
+  }
+  hipError_t e = hipGraphLaunch(ge, s.stream);  // warm-up
+  if (e == hipSuccess) e = hipEventRecord(s.ev0, s.stream);
+  for (int it = 0; it < iters && e == hipSuccess; it++) e = hipGraphLaunch(ge, s.stream);
+  if (e == hipSuccess) e = hipEventRecord(s.ev1, s.stream);
+  if (e == hipSuccess) e = hipEventSynchronize(s.ev1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, s.ev0, s.ev1);
+  (void)hipGraphExecDestroy(ge);
+  (void)hipGraphDestroy(g);
+  s.timed = false;
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "time_subset: %s", hipGetErrorString(e));
+  if (avg_launch_us) *avg_launch_us = (double)ms * 1000.0 / ((double)iters * (double)pick.size());
   return PIPER_HIP_OK;
 }

@@ -160,6 +160,8 @@ _PROTOS = {
     "piper_hip_voice_last_gpu_ms": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_double)]),
     "piper_hip_voice_slot_stream": (c_vp, [c_vp, C.c_int]),
     "piper_hip_voice_profile": (C.c_int, [c_vp, C.c_int, C.c_int, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
+    "piper_hip_voice_time_subset": (C.c_int, [c_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                              C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -535,6 +537,13 @@ class HipRuntime:
         ms = C.c_double()
         _check(self.lib.piper_hip_voice_last_gpu_ms(self.voice, slot, C.byref(ms)))
         return ms.value
+
+    def time_subset(self, slot, name_filter, iters=20):
+        """Graph replay of the launches whose name contains `name_filter`: (avg µs per launch, launches, flops, bytes)."""
+        us, n, fl, by = C.c_double(), C.c_int(), C.c_double(), C.c_double()
+        _check(self.lib.piper_hip_voice_time_subset(self.voice, slot, name_filter.encode(), iters, C.byref(us), C.byref(n),
+                                                    C.byref(fl), C.byref(by)))
+        return us.value, n.value, fl.value, by.value
 
     def profile(self, slot, iters=5, max_entries=512):
         arr = (KernelStat * max_entries)()
