@@ -9,6 +9,8 @@
 // the ±w window — so the skew is pure index arithmetic and the [N,H,T,2T−1] tensors never exist.
 // A block owns R query rows of one head; the R×T score strip lives in LDS (T ≤ 4096: the reference's own
 // --max-phonemes cap, PiperCLI.swift:394).
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -36,7 +38,17 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
                                                                const float* __restrict__ v, const float* __restrict__ ek,
                                                                const float* __restrict__ ev, float* __restrict__ out, int H, int d,
                                                                int T, int w, int64_t in_batch_stride, int64_t out_batch_stride,
-                                                               int G, int TK) {
+                                                               int G, int TK
+#ifdef PH_ATT_STAMPS
+                                                               , unsigned long long* stamps
+#endif
+                                                               ) {
+#ifdef PH_ATT_STAMPS
+#define PH_STAMP(i) do { __syncthreads(); if (stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PH_STAMP(i)
+#endif
+  PH_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int W = 2 * w + 1;
   const int ld = TK + 1;
@@ -59,6 +71,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     eks[idx] = ek[idx];
     evs[idx] = ev[idx];
   }
+  PH_STAMP(1);
   // 1. q strip, scaled by Div like the graph (query / sqrt(k_channels))
   for (int idx = tid; idx < R * d; idx += kBlock) {
     const int c = idx / R, r = idx - c * R;
@@ -66,6 +79,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     qs[r * d + c] = i < T ? qb[(int64_t)c * T + i] / scale : 0.0f;
   }
   __syncthreads();
+  PH_STAMP(2);
   // 1b. relative-key logits for the ±w window
   for (int idx = tid; idx < R * W; idx += kBlock) {
     const int r = idx / W, m = idx - r * W;
@@ -74,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     for (int c = 0; c < d; c++) s += qs[r * d + c] * eks[m * d + c];
     qe[r * W + m] = s;
   }
+  PH_STAMP(3);
   // 2. score strip, one key tile at a time
   for (int j0 = 0; j0 < T; j0 += TK) {
     const int tk = min(TK, T - j0);
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     }
   }
   __syncthreads();
+  PH_STAMP(4);
   // 3. row softmax (softmax.metal:13-41: max, exp, sum, multiply by 1/sum), one wave per row
   {
     const int lane = tid & 63, wv = tid >> 6;
@@ -124,6 +140,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
       for (int j = lane; j < T; j += 64) row[j] *= inv;
     }
   }
+  PH_STAMP(5);
   // 4. P·V: thread = (channel c, key slice g of the tile); p comes from LDS as a broadcast
   const int c4 = tid % d, g4 = tid / d;
   float pv[R];
@@ -153,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     for (int r = 0; r < R; r++) part[(g4 * R + r) * d + c4] = pv[r];
   }
   __syncthreads();
+  PH_STAMP(6);
   // 5. combine slices, add the relative-value term, store [H·d, T]
   float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * d * T;
   for (int idx = tid; idx < R * d; idx += kBlock) {
@@ -168,6 +186,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
     }
     ob[(int64_t)c * T + i] = o + rel;
   }
+  PH_STAMP(7);
 }
 
 }  // namespace
@@ -180,6 +199,9 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   if (d > kBlock) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: head_dim %d > %d", d, kBlock);
   if (T > 4096) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: T=%d exceeds 4096 (reference max-phonemes cap)", T);
   if (H > 65535 || N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: heads/batch too large");
+  // (An MFMA formulation — 16 query rows per block on v_mfma_f32_16x16x4 — was built and measured slower at every T:
+  //  47 vs 30 µs at T = 112, 233 vs 161 µs at T = 896.  The op is a chain of LDS/HBM round trips, not arithmetic, and 4×
+  //  fewer blocks each re-staging K and V lengthen the chain.)
   const int G = kBlock / d;
   const int TK = T < kKeyTile ? T : kKeyTile;
   // query rows per block: fewer rows → more blocks (short utterances have only T/R·H of them); 4 rows also keeps the score
@@ -197,10 +219,18 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   dim3 grid((unsigned)ceil_div(T, R), (unsigned)H, (unsigned)N);
   if (R == 4)
     hipLaunchKernelGGL(rel_attention_kernel<4>, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
+#ifdef PH_ATT_STAMPS
+                       out_batch_stride, G, TK, nullptr);
+#else
                        out_batch_stride, G, TK);
+#endif
   else
     hipLaunchKernelGGL(rel_attention_kernel<8>, grid, dim3(kBlock), lds, s, q, k, v, ek, ev, out, H, d, T, w, in_batch_stride,
+#ifdef PH_ATT_STAMPS
+                       out_batch_stride, G, TK, nullptr);
+#else
                        out_batch_stride, G, TK);
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;
