@@ -63,7 +63,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # PIPER_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, device-resident broadcast blob, MAX all-reduce)
+    # with a single rank — the only way to rehearse it on a one-GPU box
+    distributed = world > 1 or os.environ.get("PIPER_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -76,7 +78,10 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         # one-shot weight broadcast over RCCL/xGMI: rank 0 owns the blob, everyone else receives it in HBM
         wbuf = torch.empty(n_floats, dtype=torch.float32, device="cuda")
         if rank == 0:

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   float* sc = kv + d * ld;        // [R][T]
   float* eks = sc + R * T;        // [W][d] relative-key embeddings
   float* evs = eks + W * d;       // [W][d] relative-value embeddings
+  float* psc = evs + W * d;       // [slices-1][R][TKP] partial scores of the channel slices (≤ 256·R floats)
   const int tid = threadIdx.x;
   const int i0 = blockIdx.x * R, h = blockIdx.y, n = blockIdx.z;
   const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * d * T;
@@ -93,29 +94,56 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   for (int j0 = 0; j0 < T; j0 += TK) {
     const int tk = min(TK, T - j0);
     __syncthreads();
-#pragma unroll 4
-    for (int idx = tid; idx < d * tk; idx += kBlock) {
-      const int c = idx / tk, jj = idx - c * tk;
-      kv[c * ld + jj] = kb[(int64_t)c * T + j0 + jj];
+    // rows of the tile are dealt to the 256 threads in passes of (256 / TKP) rows, TKP = next power of two ≥ tk: index
+    // math is shifts, and the 8-way unrolled body keeps 8 independent loads per thread in flight
+    {
+      const int sh = 32 - __clz(tk - 1 > 0 ? tk - 1 : 1);  // log2(TKP) for tk ≥ 2
+      const int shc = tk <= 1 ? 0 : sh;
+      const int jj = tid & ((1 << shc) - 1), rpp = kBlock >> shc, cbase = tid >> shc;
+      if (jj < tk) {
+#pragma unroll 8
+        for (int c = cbase; c < d; c += rpp) kv[c * ld + jj] = kb[(int64_t)c * T + j0 + jj];
+      }
     }
     __syncthreads();
-    for (int jj = tid; jj < tk; jj += kBlock) {
+    // keys along the low bits of the thread id, channel slices along the high bits (256 / TKP slices): all 256 threads
+    // work and the dependent FMA chain per thread is d / slices long instead of d
+    {
+      const int sh = tk <= 1 ? 0 : 32 - __clz(tk - 1);
+      const int jj = tid & ((1 << sh) - 1), cs = tid >> sh, ns = kBlock >> sh;
+      const int cb = (int)((int64_t)d * cs / ns), ce = (int)((int64_t)d * (cs + 1) / ns);
       float acc[R];
 #pragma unroll
       for (int r = 0; r < R; r++) acc[r] = 0.0f;
+      if (jj < tk) {
 #pragma unroll 4
-      for (int c = 0; c < d; c++) {
-        const float kval = kv[c * ld + jj];
+        for (int c = cb; c < ce; c++) {
+          const float kval = kv[c * ld + jj];
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = fmaf(qs[r * d + c], kval, acc[r]);
+          for (int r = 0; r < R; r++) acc[r] = fmaf(qs[r * d + c], kval, acc[r]);
+        }
       }
-      const int j = j0 + jj;
+      if (ns > 1) {
+        __syncthreads();  // every thread is done reading part[] of an earlier phase (none) / kv stays valid
+        if (jj < tk && cs > 0) {
 #pragma unroll
-      for (int r = 0; r < R; r++) {
-        const int delta = j - (i0 + r);
-        float sv = acc[r];
-        if (delta >= -w && delta <= w) sv += qe[r * W + delta + w];
-        sc[r * T + j] = sv;
+          for (int r = 0; r < R; r++) psc[(((cs - 1) * R + r) << sh) + jj] = acc[r];
+        }
+        __syncthreads();
+      }
+      if (jj < tk && cs == 0) {
+        for (int s2 = 1; s2 < ns; s2++) {
+#pragma unroll
+          for (int r = 0; r < R; r++) acc[r] += psc[(((s2 - 1) * R + r) << sh) + jj];
+        }
+        const int j = j0 + jj;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int delta = j - (i0 + r);
+          float sv = acc[r];
+          if (delta >= -w && delta <= w) sv += qe[r * W + delta + w];
+          sc[r * T + j] = sv;
+        }
       }
     }
   }
@@ -149,10 +177,16 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   for (int j0 = 0; j0 < T; j0 += TK) {
     const int tk = min(TK, T - j0);
     __syncthreads();
-#pragma unroll 4
-    for (int idx = tid; idx < d * tk; idx += kBlock) {
-      const int c = idx / tk, jj = idx - c * tk;
-      kv[c * ld + jj] = vb[(int64_t)c * T + j0 + jj];
+    // rows of the tile are dealt to the 256 threads in passes of (256 / TKP) rows, TKP = next power of two ≥ tk: index
+    // math is shifts, and the 8-way unrolled body keeps 8 independent loads per thread in flight
+    {
+      const int sh = 32 - __clz(tk - 1 > 0 ? tk - 1 : 1);  // log2(TKP) for tk ≥ 2
+      const int shc = tk <= 1 ? 0 : sh;
+      const int jj = tid & ((1 << shc) - 1), rpp = kBlock >> shc, cbase = tid >> shc;
+      if (jj < tk) {
+#pragma unroll 8
+        for (int c = cbase; c < d; c += rpp) kv[c * ld + jj] = vb[(int64_t)c * T + j0 + jj];
+      }
     }
     __syncthreads();
     if (g4 < G) {
@@ -207,7 +241,7 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   // query rows per block: fewer rows → more blocks (short utterances have only T/R·H of them); 4 rows also keeps the score
   // strip of the longest utterances inside the 160 KiB of LDS
   const int R = (T > 2048 || (int64_t)ceil_div(T, 8) * H * N < ctx->num_cus) ? 4 : 8;
-  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T + 2 * (2 * w + 1) * d) * sizeof(float);
+  const size_t lds = (size_t)(R * d + R * (2 * w + 1) + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T + 2 * (2 * w + 1) * d + (size_t)kBlock * R) * sizeof(float);
   if (lds > 160 * 1024) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: needs %zu B of LDS", lds);
   const void* fn = R == 4 ? (const void*)rel_attention_kernel<4> : (const void*)rel_attention_kernel<8>;
   static size_t configured[2] = {0, 0};

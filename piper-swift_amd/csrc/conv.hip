@@ -589,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void conv_direct_kernel(const ConvArgs p) {
 // per thread; the (pre-activated, zero-padded) input window of the block goes through LDS once, so every input element
 // is read from memory exactly once and all of a thread's loads are independent (issued back to back).
 constexpr int kSmallCoutMax = 4, kSmallCK = 32, kSmallBT = 256;
-template <int PRO>
+template <int PRO, int COUT>
 __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int halo = (p.K - 1) * (p.dil < 0 ? -p.dil : p.dil);
@@ -601,22 +601,29 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
   const float* xb = p.x + (int64_t)n * p.x_batch_stride;
   const float* x2b = PRO == PRO_AVG3_LRELU ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
   const float* x3b = PRO == PRO_AVG3_LRELU ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
-  float acc[kSmallCoutMax];
+  float acc[COUT];
 #pragma unroll
-  for (int co = 0; co < kSmallCoutMax; co++) acc[co] = (p.bias && co < p.Cout) ? p.bias[co] : 0.0f;
+  for (int co = 0; co < COUT; co++) acc[co] = p.bias ? p.bias[co] : 0.0f;
   for (int c0 = 0; c0 < p.Cin; c0 += kSmallCK) {
     const int ck = min(kSmallCK, p.Cin - c0);
     __syncthreads();
-#pragma unroll 4
-    for (int idx = tid; idx < ck * W; idx += kSmallBT) {
-      const int c = idx / W, col = idx - c * W;
+    // channel rows × window columns: column = tid (+ 256 per extra pass), so there is no per-element division and the
+    // 8-way unrolled channel loop keeps 8 independent loads per thread in flight
+    for (int cb = 0; cb < W; cb += kSmallBT) {
+      const int col = cb + tid;
       const int pos = lo + col;
-      const int64_t off = (int64_t)(p.in_ch_base + p.in_ch_sign * (c0 + c)) * p.Lin + pos;
-      const bool ok = pos >= 0 && pos < p.Lin;
-      float v = ok ? xb[off] : 0.0f;
-      if constexpr (PRO == PRO_AVG3_LRELU) v = ok ? ((v + x2b[off]) + x3b[off]) / 3.0f : 0.0f;
-      if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
-      xs[idx] = v;
+      const bool ok = col < W && pos >= 0 && pos < p.Lin;
+      const int64_t poff = ok ? pos : 0;
+      if (col < W) {
+#pragma unroll 8
+        for (int c = 0; c < ck; c++) {
+          const int64_t off = (int64_t)(p.in_ch_base + p.in_ch_sign * (c0 + c)) * p.Lin + poff;
+          float v = xb[off];
+          if constexpr (PRO == PRO_AVG3_LRELU) v = ((v + x2b[off]) + x3b[off]) / 3.0f;
+          if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
+          xs[c * W + col] = ok ? v : 0.0f;
+        }
+      }
     }
     for (int idx = tid; idx < p.Cout * ck * p.K; idx += kSmallBT) {
       const int co = idx / (ck * p.K), rem = idx - co * ck * p.K;
@@ -627,19 +634,18 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
     const int colbase = tid - p.padL - (lo - t0);  // window column of tap 0 for this thread
     for (int c = 0; c < ck; c++) {
       const float* xr = xs + c * W + colbase;
+#pragma unroll 8
       for (int k = 0; k < p.K; k++) {
         const float xv = xr[k * p.dil];
 #pragma unroll
-        for (int co = 0; co < kSmallCoutMax; co++)
-          if (co < p.Cout) acc[co] += xv * ws[(co * kSmallCK + c) * p.K + k];
+        for (int co = 0; co < COUT; co++) acc[co] += xv * ws[(co * kSmallCK + c) * p.K + k];  // ci-major, then k: reference order
       }
     }
   }
   const int xo = t0 + tid;
   if (xo < p.Lout) {
 #pragma unroll
-    for (int co = 0; co < kSmallCoutMax; co++)
-      if (co < p.Cout) store_elem(p, n, co, xo, acc[co]);
+    for (int co = 0; co < COUT; co++) store_elem(p, n, co, xo, acc[co]);
   }
 }
 
@@ -924,11 +930,19 @@ int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
   if (a.Cout <= kSmallCoutMax && a.stride == 1 && a.groups == 1 && a.N <= 65535 && halo <= 1024 && a.K <= 64) {
     const dim3 g((unsigned)ceil_div(a.Lout, kSmallBT), (unsigned)a.N);
     const size_t lds = ((size_t)kSmallCK * (kSmallBT + halo) + (size_t)a.Cout * kSmallCK * a.K) * sizeof(float);
+#define PH_SMALL(PROV)                                                                                                   \
+  switch (a.Cout) {                                                                                                     \
+    case 1: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 1>), g, dim3(kSmallBT), lds, s, a); break;                 \
+    case 2: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 2>), g, dim3(kSmallBT), lds, s, a); break;                 \
+    case 3: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 3>), g, dim3(kSmallBT), lds, s, a); break;                 \
+    default: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 4>), g, dim3(kSmallBT), lds, s, a); break;                \
+  }
     switch (a.prologue) {
-      case PRO_NONE: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_NONE>, g, dim3(kSmallBT), lds, s, a); break;
-      case PRO_LRELU: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_LRELU>, g, dim3(kSmallBT), lds, s, a); break;
-      default: hipLaunchKernelGGL(conv_small_cout_kernel<PRO_AVG3_LRELU>, g, dim3(kSmallBT), lds, s, a); break;
+      case PRO_NONE: PH_SMALL(PRO_NONE) break;
+      case PRO_LRELU: PH_SMALL(PRO_LRELU) break;
+      default: PH_SMALL(PRO_AVG3_LRELU) break;
     }
+#undef PH_SMALL
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_small_cout launch failed: %s", hipGetErrorString(e2));
     return PIPER_HIP_OK;

@@ -13,7 +13,7 @@ int main() {
     hipMalloc(&q, n * 4); hipMalloc(&k, n * 4); hipMalloc(&v, n * 4); hipMalloc(&o, n * 4);
     hipMalloc(&ek, 9 * d * 4); hipMalloc(&ev, 9 * d * 4); hipMalloc(&st, 64);
     hipMemset(q, 0, n * 4); hipMemset(k, 0, n * 4); hipMemset(v, 0, n * 4); hipMemset(ek, 0, 9 * d * 4); hipMemset(ev, 0, 9 * d * 4);
-    const size_t lds = (size_t)(R * d + R * 9 + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T + 2 * 9 * d) * 4;
+    const size_t lds = (size_t)(R * d + R * 9 + G * R * d + (size_t)d * (TK + 1) + (size_t)R * T + 2 * 9 * d + 256 * R) * 4;
     for (int rep = 0; rep < 3; rep++) {
       hipLaunchKernelGGL(rel_attention_kernel<4>, dim3((T + R - 1) / R, H, 1), dim3(256), lds, 0, q, k, v, ek, ev, o, H, d, T, w, (int64_t)n, (int64_t)n, G, TK, st);
       hipDeviceSynchronize();
