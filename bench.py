@@ -60,6 +60,11 @@ def main():
     ap.add_argument("--slots", type=int, default=8, help="utterances in flight for the batch-throughput side metric")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): anything libraries print (RCCL's version banner, …) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -70,6 +75,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import piper_hip as ph
+    if distributed:
+        import torch  # noqa: F401  (first, so that piper_hip binds to the HIP runtime PyTorch/RCCL already use)
+        ph.set_runtime("torch")
     cfg = ph.voice_config(args.quality)
     n_floats = ph.blob_floats(cfg)
     bcast_ms = None
@@ -243,6 +251,46 @@ def main():
             dt = time.perf_counter() - a
             out["batch_throughput"] = {"slots_in_flight": S, "utterances_per_sec": round(reps * S / dt, 1),
                                        "audio_sec_per_wall_sec": round(reps * S * audio_sec / dt, 1)}
+        # ---- BASELINE configs[3]: the 32 mixed-length utterances (this rank's LPT shard; all 32 on one GPU), overlapped on slots
+        if not args.no_scale_bench:
+            from piper_hip import distributed as phd
+            factors = phd.batch32_factors()
+            mine = phd.shard_utterances([14 * f for f in factors], world)[rank]
+            by_factor = {}
+            for i in mine:
+                by_factor.setdefault(factors[i], []).append(i)
+            slot_of, nslot = {}, 0
+            for f, idxs in sorted(by_factor.items()):  # ≤ 2 slots per distinct shape, ≤ 16 slots in all
+                for k in range(min(2, len(idxs))):
+                    if nslot < 16:
+                        i2, d2, n2 = utterance(f, 3000 + 17 * f + k, cfg.inter)
+                        rt.prepare(nslot, i2, d2, n2, 0.667)
+                        slot_of.setdefault(f, []).append(nslot)
+                        nslot += 1
+            plan = []  # (slot, factor) in launch order: every utterance of the shard exactly once
+            for f, idxs in by_factor.items():
+                for k, _ in enumerate(idxs):
+                    plan.append((slot_of[f][k % len(slot_of[f])], f))
+            b_audio = sum(14 * f * 3 * hop / sr for _, f in plan)
+
+            def run_batch():
+                busy = set()
+                for sl, _ in plan:
+                    if sl in busy:  # same graph/arena again: wait for its previous utterance first
+                        rt.collect(sl, want_audio=False)
+                    rt.launch(sl)
+                    busy.add(sl)
+                for sl in busy:
+                    rt.collect(sl, want_audio=False)
+            run_batch()
+            reps = 5
+            a = time.perf_counter()
+            for _ in range(reps):
+                run_batch()
+            dt = (time.perf_counter() - a) / reps
+            out["batch32"] = {"utterances": len(plan), "audio_sec": round(b_audio, 2), "ms_per_batch": round(dt * 1e3, 3),
+                              "utterances_per_sec": round(len(plan) / dt, 1), "audio_sec_per_wall_sec": round(b_audio / dt, 1),
+                              "slots": nslot, "note": "32 mixed-length utterances (factors 1..16), LPT-sharded over ranks, graphs cached per shape"}
         # ---- CPU baseline: the oracle (C restatement, OpenMP) on the same workload, bounded sample
         if not args.no_cpu_baseline and world == 1:
             import oracle as orc
@@ -257,7 +305,10 @@ def main():
             out["cpu_baseline"] = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
                                    "cores": cores, "kind": "port",
                                    "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     rt.close()
     backend.close()
     if distributed:

@@ -790,6 +790,13 @@ bool try_launch_tile(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
   int MT = mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1);
   int NTW = MT == 4 ? 1 : 2;
   if (a.K >= 11 && MT == 4) MT = 2;  // keep the weight stage ≤ 32 KiB and CPC ≥ 2
+  {
+    static const int f_ntw = [] { const char* e = getenv("PIPER_HIP_TILE_NTW"); return e ? atoi(e) : 0; }();  // tuning experiments
+    static const int f_mt = [] { const char* e = getenv("PIPER_HIP_TILE_MT"); return e ? atoi(e) : 0; }();
+    if (f_ntw) NTW = f_ntw;
+    if (f_mt && f_mt <= MT) MT = f_mt;
+    if (MT == 4) NTW = 1;
+  }
   // enough blocks to cover the chip?
   const int64_t blocks = ceil_div(a.Lout, 128 * NTW) * ceil_div(mtiles, MT) * a.N;
   // measured (factor 64): the tile kernel wins for ≤ 64 output channels on very long rows, the streaming kernel
@@ -858,7 +865,8 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   int TM = 32;
   {
     const int64_t tiles32 = (a.gate ? ceil_div(a.Cout, 64) : ceil_div(a.Cout, 32)) * ceil_div(a.Lout, 32) * a.N;
-    if (a.w16 && tiles32 < ctx->num_cus && (!a.gate || a.Cout % 32 == 0)) TM = 16;
+    static const int force_tm = [] { const char* e = getenv("PIPER_HIP_TM"); return e ? atoi(e) : 0; }();  // tuning experiments
+    if (a.w16 && (tiles32 < ctx->num_cus || force_tm == 16) && (!a.gate || a.Cout % 32 == 0)) TM = 16;
   }
   if (TM == 16) a.w = a.w16;
   if (!a.w) PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: missing packed weights for %d-wide tiles", TM);
@@ -873,6 +881,10 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   // grow the per-wave tile only while every SIMD still gets ≥ 2 waves (a second wave is what hides load latency)
   auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, TM * nt) * a.N; };
   while (NT > 1 && waves(NT) < 2 * want) NT >>= 1;
+  {
+    static const int force_nt = [] { const char* e = getenv("PIPER_HIP_NT"); return e ? atoi(e) : 0; }();  // tuning experiments
+    if (force_nt > 0 && TM == 32 && a.Lout >= 4096) NT = force_nt;
+  }
   if ((a.gate || a.prologue == PRO_AVG3_LRELU) && NT > 2) NT = 2;  // register budget: 2 accumulator sets / 3 raw inputs
   if (a.K >= 11 && NT > 2) NT = 2;
   // Split the contraction over KS waves of one block while SIMDs would otherwise idle and every slice keeps ≥ 2 prefetch

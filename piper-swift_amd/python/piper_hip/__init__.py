@@ -165,6 +165,33 @@ _PROTOS = {
 }
 
 _lib = None
+_runtime = os.environ.get("PIPER_HIP_RUNTIME", "system")  # "system" (ROCm install), "torch" (PyTorch's bundled copy) or a path
+
+
+def set_runtime(which):
+    """Choose the HIP runtime the library binds to; must be called before the first load_library().
+
+    libpiper_hip.so is linked without a runtime of its own (-no-hip-rt). A process may hold only ONE libamdhip64 that
+    touches the GPU, so a process that also uses torch.cuda / RCCL through PyTorch must pass "torch"."""
+    global _runtime
+    if _lib is not None and which != _runtime:
+        raise RuntimeError("piper_hip: the HIP runtime is already bound to %r" % _runtime)
+    _runtime = which
+
+
+def _load_hip_runtime():
+    if _runtime == "torch":
+        import torch
+        cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")]
+    elif _runtime == "system":
+        roots = [os.environ.get("ROCM_PATH"), "/opt/rocm"]
+        cand = [os.path.join(r, "lib", n) for r in roots if r for n in ("libamdhip64.so.7", "libamdhip64.so")]
+    else:
+        cand = [_runtime]
+    for c in cand:
+        if os.path.exists(c):
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+    raise DeviceUnavailable("no HIP runtime library found (tried %s)" % ", ".join(cand))
 
 
 def load_library(path=None):
@@ -176,6 +203,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise DeviceUnavailable(f"{p} not found: build it with `make -C piper-swift_amd` "
                                 "(python __graft_entry__.py build). There is no CPU fallback.")
+    _load_hip_runtime()  # the .so carries no DT_NEEDED for libamdhip64: see set_runtime()
     lib = C.CDLL(p)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
