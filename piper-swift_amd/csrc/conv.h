@@ -20,6 +20,7 @@ enum Epilogue : int {
   EPI_WN_RES_SKIP = 4,  // co <  wn_c: y[co] = res[co] + v ; co ≥ wn_c: y2[co−wn_c] = (skip? skip[..]:0) + v
   EPI_WN_SKIP_LAST = 5, // y2[co] = (skip? skip[co]:0) + v
   EPI_CONVT = 6,        // rows are (co, phase): y[co][q·s + phase − padL] = v
+  EPI_MRF_MEAN = 7,     // r2 = v + res;  y = lrelu(((mrf_a + mrf_b) + r2) / 3, alpha2)   (last ResBlock conv of a stage)
 };
 
 struct ConvArgs {
@@ -51,6 +52,10 @@ struct ConvArgs {
   // ConvTranspose (EPI_CONVT): GEMM rows = Cout_ct·ct_stride, GEMM cols = q
   int ct_stride = 0, ct_padL = 0, ct_Lout = 0;
   int ct_shift = -1;  // log2(ct_stride) when it is a power of two (set by launch_conv_mfma)
+  // EPI_MRF_MEAN: the two other ResBlock outputs of the stage (addressed like y) and the slope applied after the mean
+  const float* mrf_a = nullptr;
+  const float* mrf_b = nullptr;
+  float alpha2 = 0.0f;
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv

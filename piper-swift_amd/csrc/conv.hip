@@ -92,6 +92,12 @@ __device__ __forceinline__ void store_mode(const ConvArgs& p, int n, int row, in
     const int idx = row * p.y_len + col;
     const float sk = p.skip ? (p.skip + (int64_t)n * p.y2_batch_stride)[idx] : 0.0f;
     (p.y2 + (int64_t)n * p.y2_batch_stride)[idx] = sk + v;
+  } else if constexpr (MODE == EPI_MRF_MEAN) {
+    const int idx = row * p.y_len + col;
+    const int64_t bo = (int64_t)n * p.y_batch_stride;
+    const float r2 = v + (p.res + bo)[idx];
+    const float m = (((p.mrf_a + bo)[idx] + (p.mrf_b + bo)[idx]) + r2) / 3.0f;
+    (p.y + bo)[idx] = lrelu(m, p.alpha2);
   } else if constexpr (MODE == EPI_CONVT) {
     int co, ph;
     if (p.ct_shift >= 0) {  // stride is a power of two in every Piper voice (8, 8, 4 / 8, 8, 2, 2)
@@ -115,6 +121,7 @@ __device__ __forceinline__ void store_elem(const ConvArgs& p, int n, int row, in
     case EPI_WN_RES_SKIP: store_mode<EPI_WN_RES_SKIP>(p, n, row, col, v); break;
     case EPI_WN_SKIP_LAST: store_mode<EPI_WN_SKIP_LAST>(p, n, row, col, v); break;
     case EPI_CONVT: store_mode<EPI_CONVT>(p, n, row, col, v); break;
+    case EPI_MRF_MEAN: store_mode<EPI_MRF_MEAN>(p, n, row, col, v); break;
   }
 }
 
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     case EPI_WN_RES_SKIP: emit(std::integral_constant<int, EPI_WN_RES_SKIP>{}); break;
     case EPI_WN_SKIP_LAST: emit(std::integral_constant<int, EPI_WN_SKIP_LAST>{}); break;
     case EPI_CONVT: emit(std::integral_constant<int, EPI_CONVT>{}); break;
+    case EPI_MRF_MEAN: emit(std::integral_constant<int, EPI_MRF_MEAN>{}); break;
   }
 }
 
@@ -516,6 +524,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
     case EPI_WN_RES_SKIP: emit(std::integral_constant<int, EPI_WN_RES_SKIP>{}); break;
     case EPI_WN_SKIP_LAST: emit(std::integral_constant<int, EPI_WN_SKIP_LAST>{}); break;
     case EPI_CONVT: emit(std::integral_constant<int, EPI_CONVT>{}); break;
+    case EPI_MRF_MEAN: emit(std::integral_constant<int, EPI_MRF_MEAN>{}); break;
   }
 }
 

@@ -395,6 +395,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
   piper_hip_ctx* ctx = v->ctx;
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
   slot_release(v, s, false);
+  static const bool parallel_rb = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F;
@@ -599,6 +600,9 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       f.kind = Step::FORK;
       s.steps.push_back(f);
     }
+    float* m = ar.f32((size_t)S.Cout * Lo);  // lrelu(mean of the three ResBlock outputs): input of the next stage
+    if (ar.rc) return ar.rc;
+    const float mean_alpha = (u + 1 == c.n_ups) ? 0.01f : 0.1f;  // F.leaky_relu default slope before conv_post
     for (int j = 0; j < c.n_rb; j++) {
       s.cur_lane = j < 3 ? j : 0;
       const int K = c.rb_kernels[j];
@@ -606,18 +610,29 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       for (int di = 0; di < c.rb_n_dil; di++) {
         const int dil = c.rb_dilations[j][di];
         const bool lastd = di + 1 == c.rb_n_dil;
-        float* dst = lastd ? r[j] : ((di & 1) ? tmp2[j] : tmp[j]);
+        // the very last conv of the stage folds the MRF mean + LeakyReLU into its epilogue (r0, r1 are complete by then)
+        const bool fuse_mean = lastd && j + 1 == c.n_rb && !parallel_rb;
+        float* dst = lastd ? (fuse_mean ? m : r[j]) : ((di & 1) ? tmp2[j] : tmp[j]);
         const std::string nm = p + "rb" + std::to_string(j) + ".c" + std::to_string(di);
         auto rbconv = [&](const float* in, const float* res, float* out, int dl) {
           ConvArgs a = plain(in, out, S.Cout, S.Cout, Lo);
           a.dil = dl; a.padL = (K * dl - dl) / 2; a.prologue = PRO_LRELU; a.alpha = 0.1f; a.res = res;
           return a;
         };
+        auto with_mean = [&](ConvArgs a) {
+          if (fuse_mean) {
+            a.epilogue = EPI_MRF_MEAN;
+            a.mrf_a = r[0]; a.mrf_b = r[1]; a.alpha2 = mean_alpha;
+          }
+          return a;
+        };
         if (c.resblock_type == 1) {
           add_conv(v, s, nm + "a_lrelu_conv", S.rb[j][2 * di], rbconv(src, nullptr, mid[j], dil), Lo);
-          add_conv(v, s, nm + "b_lrelu_conv_res", S.rb[j][2 * di + 1], rbconv(mid[j], src, dst, 1), Lo);
+          add_conv(v, s, nm + (fuse_mean ? "b_lrelu_conv_res_mrfmean" : "b_lrelu_conv_res"), S.rb[j][2 * di + 1],
+                   with_mean(rbconv(mid[j], src, dst, 1)), Lo);
         } else {
-          add_conv(v, s, nm + "_lrelu_conv_res", S.rb[j][di], rbconv(src, src, dst, dil), Lo);
+          add_conv(v, s, nm + (fuse_mean ? "_lrelu_conv_res_mrfmean" : "_lrelu_conv_res"), S.rb[j][di],
+                   with_mean(rbconv(src, src, dst, dil)), Lo);
         }
         src = dst;
       }
@@ -629,22 +644,19 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       jn.kind = Step::JOIN;
       s.steps.push_back(jn);
     }
-    {
-      float* m = ar.f32((size_t)S.Cout * Lo);
-      if (ar.rc) return ar.rc;
+    if (parallel_rb) {  // branches finish independently: the mean needs its own launch after the join
       Step st;
       st.name = p + "mrf_mean_lrelu";
       const float *r0 = r[0], *r1 = r[1], *r2 = r[2];
       const int64_t cnt = (int64_t)S.Cout * Lo;
-      const float alpha = (u + 1 == c.n_ups) ? 0.01f : 0.1f;  // F.leaky_relu default slope before conv_post
       st.run = [=](hipStream_t q) {
         const int grid = (int)std::min<int64_t>(ceil_div(cnt, (int64_t)kBlock * 4), 2048);
-        hipLaunchKernelGGL(mrf_mean_lrelu_kernel, dim3(grid), dim3(kBlock), 0, q, r0, r1, r2, m, cnt, alpha);
+        hipLaunchKernelGGL(mrf_mean_lrelu_kernel, dim3(grid), dim3(kBlock), 0, q, r0, r1, r2, m, cnt, mean_alpha);
         return PIPER_HIP_OK;
       };
       s.steps.push_back(st);
-      cur[0] = m; cur[1] = nullptr; cur[2] = nullptr;
     }
+    cur[0] = m; cur[1] = nullptr; cur[2] = nullptr;
     cur_is_mrf = true;
     L = Lo;
   }
