@@ -179,3 +179,34 @@ def test_overlapped_slots(rt_medium, voices):
         rt_medium.launch(4 + s)
     for s, (ids, dur, noise) in enumerate(utts):
         assert_close(rt_medium.collect(4 + s), orc.synthesize(cfg, blob, ids, dur, noise, 0.667), WAVE_TOL, f"slot {4 + s}")
+
+
+def test_max_phonemes_cap(rt_medium):
+    """4096 ids is the reference's --max-phonemes cap (PiperCLI.swift:394): the largest accepted utterance must run
+    (attention with a 4096-wide score strip, 1 M-sample decoder rows) and stay finite and deterministic."""
+    T = 4096
+    ids = (kd.FIXTURE_IDS * 300)[:T]
+    dur = [1] * T
+    noise = kd.sym(SD + 300, (192, T), 1.0)
+    rt_medium.prepare(9, ids, dur, noise, 0.667)
+    rt_medium.launch(9)
+    a = rt_medium.collect(9)
+    assert a.size == T * 256 and np.all(np.isfinite(a)) and np.max(np.abs(a)) <= 1.0
+    rt_medium.launch(9)
+    assert np.array_equal(a, rt_medium.collect(9))
+
+
+def test_time_subset_and_profile(rt_medium):
+    ids, dur = kd.FIXTURE_IDS * 2, [3] * 28
+    rt_medium.prepare(10, ids, dur, None, 0.667)
+    rt_medium.launch(10)
+    ref = rt_medium.collect(10)
+    us, n, fl, by = rt_medium.time_subset(10, "conv_mfma", iters=3)
+    assert n > 60 and us > 0 and fl > 1e9 and by > 1e6
+    us_all, n_all, fl_all, _ = rt_medium.time_subset(10, "", iters=3)
+    assert n_all > n and fl_all >= fl
+    st = rt_medium.profile(10, iters=2)
+    assert any(s["name"].startswith("(event floor") for s in st) and sum(s["flops"] for s in st) == pytest.approx(fl_all)
+    # profiling replays non-idempotent steps; a normal launch afterwards must still be exact
+    rt_medium.launch(10)
+    assert np.array_equal(ref, rt_medium.collect(10))
