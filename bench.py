@@ -313,6 +313,7 @@ def main():
     backend.close()
     if distributed:
         import torch.distributed as dist
+        dist.barrier()  # rank 0 may still have been collecting its side metrics
         dist.destroy_process_group()
 
 
