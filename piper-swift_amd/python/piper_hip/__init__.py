@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libpiper_hip.so"))
+LIB_NORT_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libpiper_hip_nort.so"))  # linked with -no-hip-rt
 
 # ---- errors: ExecutionError (CPUBackend.swift:3-17) ----
 
@@ -165,33 +166,32 @@ _PROTOS = {
 }
 
 _lib = None
-_runtime = os.environ.get("PIPER_HIP_RUNTIME", "system")  # "system" (ROCm install), "torch" (PyTorch's bundled copy) or a path
+_runtime = os.environ.get("PIPER_HIP_RUNTIME", "system")  # "system" (ROCm install) or "torch" (PyTorch's bundled copy)
 
 
 def set_runtime(which):
-    """Choose the HIP runtime the library binds to; must be called before the first load_library().
+    """Choose the HIP runtime the library runs on; must be called before the first load_library().
 
-    libpiper_hip.so is linked without a runtime of its own (-no-hip-rt). A process may hold only ONE libamdhip64 that
-    touches the GPU, so a process that also uses torch.cuda / RCCL through PyTorch must pass "torch"."""
+    A process may hold only ONE libamdhip64 that touches the GPU.  "system" loads libpiper_hip.so, which depends on the
+    ROCm install's runtime.  "torch" is for processes that also drive the GPU through PyTorch (torch.cuda, RCCL): PyTorch's
+    bundled libamdhip64 is made global and libpiper_hip_nort.so (linked with -no-hip-rt) binds to it."""
     global _runtime
+    if which not in ("system", "torch"):
+        raise ValueError("runtime must be 'system' or 'torch'")
     if _lib is not None and which != _runtime:
         raise RuntimeError("piper_hip: the HIP runtime is already bound to %r" % _runtime)
     _runtime = which
 
 
-def _load_hip_runtime():
+def _library_path():
     if _runtime == "torch":
         import torch
-        cand = [os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")]
-    elif _runtime == "system":
-        roots = [os.environ.get("ROCM_PATH"), "/opt/rocm"]
-        cand = [os.path.join(r, "lib", n) for r in roots if r for n in ("libamdhip64.so.7", "libamdhip64.so")]
-    else:
-        cand = [_runtime]
-    for c in cand:
-        if os.path.exists(c):
-            return C.CDLL(c, mode=C.RTLD_GLOBAL)
-    raise DeviceUnavailable("no HIP runtime library found (tried %s)" % ", ".join(cand))
+        rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if not os.path.exists(rt):
+            raise DeviceUnavailable("PyTorch's HIP runtime not found at %s" % rt)
+        C.CDLL(rt, mode=C.RTLD_GLOBAL)  # already loaded by torch; this only promotes it to the global symbol scope
+        return LIB_NORT_PATH
+    return LIB_PATH
 
 
 def load_library(path=None):
@@ -199,11 +199,10 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or _library_path()
     if not os.path.exists(p):
         raise DeviceUnavailable(f"{p} not found: build it with `make -C piper-swift_amd` "
                                 "(python __graft_entry__.py build). There is no CPU fallback.")
-    _load_hip_runtime()  # the .so carries no DT_NEEDED for libamdhip64: see set_runtime()
     lib = C.CDLL(p)
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
