@@ -251,6 +251,26 @@ def main():
             dt = time.perf_counter() - a
             out["batch_throughput"] = {"slots_in_flight": S, "utterances_per_sec": round(reps * S / dt, 1),
                                        "audio_sec_per_wall_sec": round(reps * S * audio_sec / dt, 1)}
+        # ---- same-shape batching: N utterances per launch share one schedule (batch dimension in every kernel)
+        if not args.no_scale_bench:
+            NBATCH = 8
+            bu = [utterance(args.factor, 700 + b, cfg.inter) for b in range(NBATCH)]
+            for sl in (14, 15):
+                rt.prepare_batch(sl, bu, 0.667)
+            for sl in (14, 15):
+                rt.launch(sl)
+            for sl in (14, 15):
+                rt.collect(sl, want_audio=False)
+            reps = 20
+            a = time.perf_counter()
+            for _ in range(reps):
+                rt.launch(14); rt.launch(15)
+                rt.collect(14, want_audio=False); rt.collect(15, want_audio=False)
+            dt = time.perf_counter() - a
+            us_b, n_b, fl_b, _ = rt.time_subset(14, "conv_mfma", iters=10)
+            out["batched_same_shape"] = {"batch": NBATCH, "slots_in_flight": 2, "utterances_per_sec": round(reps * 2 * NBATCH / dt, 1),
+                                         "audio_sec_per_wall_sec": round(reps * 2 * NBATCH * audio_sec / dt, 1),
+                                         "conv_kernel_tflops": round(fl_b / (us_b * n_b * 1e-6) / 1e12, 2) if us_b > 0 else None}
         # ---- BASELINE configs[3]: the 32 mixed-length utterances (this rank's LPT shard; all 32 on one GPU), overlapped on slots
         if not args.no_scale_bench:
             from piper_hip import distributed as phd

@@ -285,9 +285,15 @@ int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_ut
  * inputs; returns a slot id ≥ 0. A slot is an independent stream + arena, so several prepared utterances
  * can be launched back-to-back and overlap on the GPU. */
 int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot);
+/* The same for `n` utterances of identical shape (equal T and equal Σ durations): they share ONE schedule whose kernels
+ * carry a batch dimension, so a launch costs what one utterance costs in dispatches. Utterances of different shapes go
+ * to different slots (bucket by shape). `collect` then returns the n waveforms back to back. */
+int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot);
+/* Batch size of a prepared slot (0 if the slot is not prepared). */
+int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot);
 /* Enqueue the prepared slot's forward pass (one hipGraphLaunch). No host sync. */
 int piper_hip_voice_launch(piper_hip_voice* v, int slot);
-/* Wait for the slot and copy the waveform [num_samples] to host (NULL = just wait). */
+/* Wait for the slot and copy the waveform(s) [batch · num_samples] to host (NULL = just wait). */
 int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples);
 /* prepare + launch + collect: PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80). */
 int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u, float* host_audio,

@@ -37,6 +37,8 @@ constexpr int kMaxSlots = 16;
 // x[c][t] = emb[ids[t]][c] * sqrt(H): Gather + Mul + Transpose of the graph head (GraphExecutor.swift:653-666)
 __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
                                                        float* __restrict__ x, int H, int T, int n_vocab, float scale) {
+  ids += (int64_t)blockIdx.y * T;  // batch item
+  x += (int64_t)blockIdx.y * H * T;
   const int total = H * T;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
     const int c = i / T, t = i - c * T;
@@ -52,7 +54,13 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict
 __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __restrict__ stats, const int32_t* __restrict__ frame2id,
                                                               const float* __restrict__ noise, float* __restrict__ zp, float* __restrict__ zp_tap,
                                                               int I, int T, int F, const float* __restrict__ noise_scale_dev) {
-  const float noise_scale = noise_scale_dev[0];  // per-utterance scalar lives in device memory so a replayed graph sees it
+  const int nb = blockIdx.y;  // batch item
+  stats += (int64_t)nb * 2 * I * T;
+  frame2id += (int64_t)nb * F;
+  noise += (int64_t)nb * I * F;
+  zp += (int64_t)nb * I * F;
+  zp_tap += (int64_t)nb * I * F;
+  const float noise_scale = noise_scale_dev[nb];  // per-utterance scalar lives in device memory so a replayed graph sees it
   const int64_t total = (int64_t)I * F;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int c = (int)(i / F), f = (int)(i - (int64_t)c * F);
@@ -91,6 +99,8 @@ __global__ __launch_bounds__(kBlock) void mrf_mean_lrelu_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(kBlock) void flip_channels_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int L) {
+  x += (int64_t)blockIdx.y * C * L;  // batch item
+  y += (int64_t)blockIdx.y * C * L;
   const int64_t total = (int64_t)C * L;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int c = (int)(i / L), l = (int)(i - (int64_t)c * L);
@@ -130,14 +140,14 @@ struct Slot {
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int T = -1, F = -1;
+  int T = -1, F = -1, NB = 1;  // NB utterances of identical (T, F) share one schedule (batch dimension of every kernel)
   // device buffers
   std::vector<void*> owned;
   int64_t* ids = nullptr;
   int32_t* frame2id = nullptr;
   float* noise = nullptr;
   float* noise_scale = nullptr;  // [1] device
-  float h_noise_scale = 0.f;
+  std::vector<float> h_noise_scale;
   float* audio = nullptr;
   int64_t n_samples = 0;
   std::vector<Step> steps;
@@ -383,14 +393,14 @@ void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW&
   st.name = name;
   const bool mfma = w.mfma;
   st.run = [ctx, a, mfma](hipStream_t q) { return mfma ? launch_conv_mfma(ctx, q, a) : launch_conv_direct(ctx, q, a); };
-  st.flops = conv_flops(w.Cout, w.Cin, w.K, Lout_for_work);
-  st.bytes = conv_bytes(w.Cin, a.gate ? w.Cout / 2 : w.Cout, w.K, Lout_for_work);
+  st.flops = a.N * conv_flops(w.Cout, w.Cin, w.K, Lout_for_work);
+  st.bytes = a.N * conv_bytes(w.Cin, a.gate ? w.Cout / 2 : w.Cout, w.K, Lout_for_work);
   st.lane = s.cur_lane;
   st.tag = mfma ? "conv_mfma" : "conv_small";
   s.steps.push_back(std::move(st));
 }
 
-int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
+int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   const piper_hip_voice_config& c = v->cfg;
   piper_hip_ctx* ctx = v->ctx;
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
@@ -398,26 +408,27 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
   static const bool parallel_rb = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
-  s.T = T; s.F = F;
-  s.ids = (int64_t*)ar.raw((size_t)T * sizeof(int64_t));
-  s.frame2id = (int32_t*)ar.raw((size_t)F * sizeof(int32_t));
-  s.noise = ar.f32((size_t)I * F);
-  s.noise_scale = ar.f32(1);
+  s.T = T; s.F = F; s.NB = NB;
+  const size_t B = (size_t)NB;
+  s.ids = (int64_t*)ar.raw(B * T * sizeof(int64_t));
+  s.frame2id = (int32_t*)ar.raw(B * F * sizeof(int32_t));
+  s.noise = ar.f32(B * I * F);
+  s.noise_scale = ar.f32(B);
   // ---------------- text encoder
-  float* x = ar.f32((size_t)H * T);
-  float* x1 = ar.f32((size_t)H * T);
-  float* qkv = ar.f32((size_t)3 * H * T);
-  float* att = ar.f32((size_t)H * T);
-  float* y = ar.f32((size_t)H * T);
-  float* ff = ar.f32((size_t)c.ffn * T);
-  float* stats = ar.f32((size_t)2 * I * T);
-  float* zp = ar.f32((size_t)I * F);
-  float* zflip = ar.f32((size_t)I * F);
-  float* zp_tap = ar.f32((size_t)I * F);
-  float* h = ar.f32((size_t)H * F);
-  float* acts = ar.f32((size_t)H * F);
-  float* skip = ar.f32((size_t)H * F);
-  float* dec0 = ar.f32((size_t)c.up_initial * F);
+  float* x = ar.f32(B * (size_t)H * T);
+  float* x1 = ar.f32(B * (size_t)H * T);
+  float* qkv = ar.f32(B * (size_t)3 * H * T);
+  float* att = ar.f32(B * (size_t)H * T);
+  float* y = ar.f32(B * (size_t)H * T);
+  float* ff = ar.f32(B * (size_t)c.ffn * T);
+  float* stats = ar.f32(B * (size_t)2 * I * T);
+  float* zp = ar.f32(B * (size_t)I * F);
+  float* zflip = ar.f32(B * (size_t)I * F);
+  float* zp_tap = ar.f32(B * (size_t)I * F);
+  float* h = ar.f32(B * (size_t)H * F);
+  float* acts = ar.f32(B * (size_t)H * F);
+  float* skip = ar.f32(B * (size_t)H * F);
+  float* dec0 = ar.f32(B * (size_t)c.up_initial * F);
   if (ar.rc) return ar.rc;
   {
     Step st;
@@ -428,14 +439,14 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     const float scale = sqrtf((float)H);
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)H * T, kBlock), 2048);
-      hipLaunchKernelGGL(embed_kernel, dim3(grid), dim3(kBlock), 0, q, ids, emb, x, H, T, nv, scale);
+      hipLaunchKernelGGL(embed_kernel, dim3(grid, NB), dim3(kBlock), 0, q, ids, emb, x, H, T, nv, scale);
       return PIPER_HIP_OK;
     };
     s.steps.push_back(st);
   }
   auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L) {
     ConvArgs a;
-    a.x = in; a.y = out; a.N = 1; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
+    a.x = in; a.y = out; a.N = NB; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
     a.y_len = L;
     return a;
   };
@@ -451,12 +462,12 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       const float *ek = L.ek, *ev = L.ev;
       const int nh = c.n_heads, w = c.window;
       st.run = [=](hipStream_t q) {
-        return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, 1, nh, d, T, w,
+        return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
                                     (int64_t)3 * H * T, (int64_t)H * T);
       };
       // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
-      st.flops = 2.0 * nh * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
-      st.bytes = 4.0 * nh * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
+      st.flops = NB * 2.0 * nh * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
+      st.bytes = NB * 4.0 * nh * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
       s.steps.push_back(st);
     }
     add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T), T);
@@ -466,7 +477,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       st.tag = "add_layernorm";
       st.run = [=](hipStream_t q) {
         float* o = out;
-        return piper_hip_add_layernorm_f32(ctx, a, b, g, be, 1, H, T, 1e-5f, &o, (piper_hip_stream)q);
+        return piper_hip_add_layernorm_f32(ctx, a, b, g, be, NB, H, T, 1e-5f, &o, (piper_hip_stream)q);
       };
       s.steps.push_back(st);
     };
@@ -482,10 +493,12 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     }
     add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
   }
-  s.taps["enc_out"] = {x, (size_t)H * T};
+  s.taps["enc_out"] = {x, B * H * T};
   add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T), T);
-  s.taps["m_p"] = {stats, (size_t)I * T};
-  s.taps["logs_p"] = {stats + (size_t)I * T, (size_t)I * T};
+  if (NB == 1) {  // halves of the [2I, T] projection; for a batch read "enc_out"/"z_p" instead
+    s.taps["m_p"] = {stats, (size_t)I * T};
+    s.taps["logs_p"] = {stats + (size_t)I * T, (size_t)I * T};
+  }
   {
     Step st;
     st.name = "expand_noise";
@@ -494,15 +507,15 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     const float* nsd = s.noise_scale;
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
-      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd);
+      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid, NB), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd);
       return PIPER_HIP_OK;
     };
     // path expansion counted as the reference's two MatMuls mm(1,F,192,T)
-    st.flops = 2.0 * 2.0 * F * (double)I * T;
-    st.bytes = 2.0 * 4.0 * ((double)F * T + (double)T * I + (double)F * I);
+    st.flops = NB * 2.0 * 2.0 * F * (double)I * T;
+    st.bytes = NB * 2.0 * 4.0 * ((double)F * T + (double)T * I + (double)F * I);
     s.steps.push_back(st);
   }
-  s.taps["z_p"] = {zp_tap, (size_t)I * F};
+  s.taps["z_p"] = {zp_tap, B * I * F};
   // ---------------- flow (reverse)
   bool flipped = false;
   const int half = I / 2;
@@ -544,36 +557,36 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     st.name = "flow.final_flip";
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
-      hipLaunchKernelGGL(flip_channels_kernel, dim3(grid), dim3(kBlock), 0, q, zp, zflip, I, F);
+      hipLaunchKernelGGL(flip_channels_kernel, dim3(grid, NB), dim3(kBlock), 0, q, zp, zflip, I, F);
       return PIPER_HIP_OK;
     };
     s.steps.push_back(st);
     z = zflip;
   }
-  s.taps["z"] = {z, (size_t)I * F};
+  s.taps["z"] = {z, B * I * F};
   // ---------------- HiFi-GAN generator
   {
     ConvArgs a = plain(z, dec0, I, c.up_initial, F);
     a.padL = 3;
     add_conv(v, s, "dec.conv_pre", v->conv_pre, a, F);
   }
-  s.taps["dec_pre"] = {dec0, (size_t)c.up_initial * F};
+  s.taps["dec_pre"] = {dec0, B * c.up_initial * F};
   const float* cur[3] = {dec0, nullptr, nullptr};
   bool cur_is_mrf = false;
   int L = F;
   for (int u = 0; u < c.n_ups; u++) {
     const auto& S = v->stages[u];
     const int Lo = L * S.stride;  // (L−1)s − 2·pad + K = L·s for the even (K−s) the config check enforces
-    float* up = ar.f32((size_t)S.Cout * Lo);
+    float* up = ar.f32(B * S.Cout * Lo);
     float* r[PIPER_HIP_MAX_RB];
     float* tmp[PIPER_HIP_MAX_RB];
     float* tmp2[PIPER_HIP_MAX_RB];
     float* mid[PIPER_HIP_MAX_RB];
     for (int j = 0; j < c.n_rb; j++) {
-      r[j] = ar.f32((size_t)S.Cout * Lo);
-      tmp[j] = ar.f32((size_t)S.Cout * Lo);
-      tmp2[j] = c.rb_n_dil > 2 ? ar.f32((size_t)S.Cout * Lo) : nullptr;
-      mid[j] = c.resblock_type == 1 ? ar.f32((size_t)S.Cout * Lo) : nullptr;
+      r[j] = ar.f32(B * S.Cout * Lo);
+      tmp[j] = ar.f32(B * S.Cout * Lo);
+      tmp2[j] = c.rb_n_dil > 2 ? ar.f32(B * S.Cout * Lo) : nullptr;
+      mid[j] = c.resblock_type == 1 ? ar.f32(B * S.Cout * Lo) : nullptr;
     }
     if (ar.rc) return ar.rc;
     const std::string p = "dec.s" + std::to_string(u) + ".";
@@ -582,7 +595,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       a.x = cur[0];
       a.prologue = cur_is_mrf ? PRO_NONE : PRO_LRELU;  // the MRF mean kernel already applied LeakyReLU(0.1)
       a.alpha = 0.1f;
-      a.y = up; a.N = 1; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
+      a.y = up; a.N = NB; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
       a.x_batch_stride = (int64_t)S.Cin * L; a.y_batch_stride = (int64_t)S.Cout * Lo; a.y_len = Lo;
       a.epilogue = EPI_CONVT; a.ct_stride = S.stride; a.ct_padL = S.pad; a.ct_Lout = Lo;
       a.w = S.up.w; a.w16 = S.up.w16; a.bias = S.up.bias; a.Cin = S.up.Cin; a.Cout = S.up.Cout; a.K = S.up.K;
@@ -590,8 +603,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       st.name = p + "lrelu_convT";
       st.tag = "conv_mfma";
       st.run = [ctx, a](hipStream_t q) { return launch_conv_mfma(ctx, q, a); };
-      st.flops = 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
-      st.bytes = 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
+      st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
+      st.bytes = NB * 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
       s.steps.push_back(st);
     }
     {  // the stage's ResBlocks read the same `up` and write disjoint buffers: run them as parallel graph branches
@@ -600,7 +613,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       f.kind = Step::FORK;
       s.steps.push_back(f);
     }
-    float* m = ar.f32((size_t)S.Cout * Lo);  // lrelu(mean of the three ResBlock outputs): input of the next stage
+    float* m = ar.f32(B * S.Cout * Lo);  // lrelu(mean of the three ResBlock outputs): input of the next stage
     if (ar.rc) return ar.rc;
     const float mean_alpha = (u + 1 == c.n_ups) ? 0.01f : 0.1f;  // F.leaky_relu default slope before conv_post
     for (int j = 0; j < c.n_rb; j++) {
@@ -648,7 +661,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
       Step st;
       st.name = p + "mrf_mean_lrelu";
       const float *r0 = r[0], *r1 = r[1], *r2 = r[2];
-      const int64_t cnt = (int64_t)S.Cout * Lo;
+      const int64_t cnt = (int64_t)NB * S.Cout * Lo;
       st.run = [=](hipStream_t q) {
         const int grid = (int)std::min<int64_t>(ceil_div(cnt, (int64_t)kBlock * 4), 2048);
         hipLaunchKernelGGL(mrf_mean_lrelu_kernel, dim3(grid), dim3(kBlock), 0, q, r0, r1, r2, m, cnt, mean_alpha);
@@ -661,13 +674,13 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F) {
     L = Lo;
   }
   s.n_samples = L;
-  s.audio = ar.f32((size_t)L);
+  s.audio = ar.f32(B * L);
   if (ar.rc) return ar.rc;
   {
     ConvArgs a;
     a.x = cur[0];
     a.prologue = PRO_NONE;  // LeakyReLU(0.01) of the MRF mean was applied by the mean kernel
-    a.y = s.audio; a.N = 1; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.y = s.audio; a.N = NB; a.padL = 3; a.Lin = L; a.Lout = L;
     a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
     a.epilogue = EPI_TANH;
     add_conv(v, s, "dec.conv_post_tanh", v->conv_post, a, L);
@@ -800,47 +813,59 @@ PH_EXPORT int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const pi
   return F * v->hop;
 }
 
-PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot) {
+PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot) {
+  if (!v || !utts) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
   int64_t F64 = 0;
-  int rc = check_utt(v, u, &F64);
+  int rc = check_utt(v, &utts[0], &F64);
   if (rc) return rc;
+  for (int b = 1; b < n; b++) {  // one schedule serves the batch: every utterance must have the same (T, F)
+    int64_t Fb = 0;
+    if ((rc = check_utt(v, &utts[b], &Fb))) return rc;
+    if (utts[b].t != utts[0].t || Fb != F64)
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch item %d has (T=%d, F=%lld); the batch is (T=%d, F=%lld) — bucket utterances by shape", b,
+              utts[b].t, (long long)Fb, utts[0].t, (long long)F64);
+  }
   if (slot < 0 || slot >= kMaxSlots) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d out of range [0,%d)", slot, kMaxSlots);
+  if (F64 * v->hop * n > 0x3fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch too large");
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   Slot& s = v->slots[slot];
   if ((rc = slot_init(v, s))) return rc;
-  const int T = u->t, F = (int)F64;
+  const int T = utts[0].t, F = (int)F64, I = v->cfg.inter;
   // the previous launch on this slot may still be reading the inputs
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
-  const bool rebuild = (s.T != T || s.F != F || !s.exec);
+  const bool rebuild = (s.T != T || s.F != F || s.NB != n || !s.exec);
   if (rebuild) {
-    if ((rc = build_schedule(v, s, T, F))) { slot_release(v, s, false); return rc; }
+    if ((rc = build_schedule(v, s, T, F, n))) { slot_release(v, s, false); return rc; }
   }
-  if (s.h_cap_t < (size_t)T) {
+  if (s.h_cap_t < (size_t)T * n) {
     if (s.h_ids) (void)hipHostFree(s.h_ids);
-    PH_HIP(hipHostMalloc((void**)&s.h_ids, (size_t)T * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
-    s.h_cap_t = T;
+    PH_HIP(hipHostMalloc((void**)&s.h_ids, (size_t)T * n * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
+    s.h_cap_t = (size_t)T * n;
   }
-  if (s.h_cap_f < (size_t)F) {
+  if (s.h_cap_f < (size_t)F * n) {
     if (s.h_f2i) (void)hipHostFree(s.h_f2i);
-    PH_HIP(hipHostMalloc((void**)&s.h_f2i, (size_t)F * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
-    s.h_cap_f = F;
+    PH_HIP(hipHostMalloc((void**)&s.h_f2i, (size_t)F * n * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
+    s.h_cap_f = (size_t)F * n;
   }
-  memcpy(s.h_ids, u->phoneme_ids, (size_t)T * sizeof(int64_t));
-  {
+  s.h_noise_scale.resize(n);
+  for (int b = 0; b < n; b++) {
+    const piper_hip_utterance* u = &utts[b];
+    memcpy(s.h_ids + (size_t)b * T, u->phoneme_ids, (size_t)T * sizeof(int64_t));
     int f = 0;  // generate_path: frame f belongs to the phoneme whose cumulative duration covers it
     for (int t = 0; t < T; t++)
-      for (int j = 0; j < u->durations[t]; j++) s.h_f2i[f++] = t;
+      for (int j = 0; j < u->durations[t]; j++) s.h_f2i[(size_t)b * F + f++] = t;
+    s.h_noise_scale[b] = u->noise_scale;
+    if (u->noise)
+      PH_HIP(hipMemcpyAsync(s.noise + (size_t)b * I * F, u->noise, (size_t)I * F * sizeof(float), hipMemcpyHostToDevice, s.stream),
+             PIPER_HIP_ERR_LAUNCH);
+    else
+      PH_HIP(hipMemsetAsync(s.noise + (size_t)b * I * F, 0, (size_t)I * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
   }
-  s.h_noise_scale = u->noise_scale;
-  PH_HIP(hipMemcpyAsync(s.noise_scale, &s.h_noise_scale, sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-  if (u->noise)
-    PH_HIP(hipMemcpyAsync(s.noise, u->noise, (size_t)v->cfg.inter * F * sizeof(float), hipMemcpyHostToDevice, s.stream),
-           PIPER_HIP_ERR_LAUNCH);
-  else
-    PH_HIP(hipMemsetAsync(s.noise, 0, (size_t)v->cfg.inter * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // u->noise is caller memory
+  PH_HIP(hipMemcpyAsync(s.noise_scale, s.h_noise_scale.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * n * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * n * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // noise / scalars come from caller memory
   if (rebuild) {
     // one eager pass validates every launch (and sets kernel attributes) before capture
     if ((rc = run_schedule(s, s.stream, false))) { slot_release(v, s, false); return rc; }
@@ -870,6 +895,15 @@ PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_uttera
   return slot;
 }
 
+PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot) {
+  return piper_hip_voice_prepare_batch(v, u, 1, slot);
+}
+
+PH_EXPORT int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot) {
+  if (!v || slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) return 0;
+  return v->slots[slot].NB;
+}
+
 PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
   if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
@@ -886,8 +920,9 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
   if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   Slot& s = v->slots[slot];
   if (host_audio) {
-    if (max_samples < s.n_samples) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)s.n_samples);
-    PH_HIP(hipMemcpyAsync(host_audio, s.audio, (size_t)s.n_samples * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
+    const int64_t total = s.n_samples * s.NB;  // batch items back to back
+    if (max_samples < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)total);
+    PH_HIP(hipMemcpyAsync(host_audio, s.audio, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
   }
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;

@@ -154,6 +154,8 @@ _PROTOS = {
     "piper_hip_voice_destroy": (None, [c_vp]),
     "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
     "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
+    "piper_hip_voice_prepare_batch": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
+    "piper_hip_voice_batch_size": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_launch": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_collect": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64]),
     "piper_hip_voice_synthesize": (C.c_int, [c_vp, C.POINTER(Utterance), c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -537,6 +539,22 @@ class HipRuntime:
         u, k = self._utt(phonemeIDs, durations, noise, noiseScale)
         self._keep[slot] = (k, int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u))))
         rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def prepare_batch(self, slot, utterances, noiseScale=0.667):
+        """utterances: list of (phonemeIDs, durations, noise-or-None), all with the same T and the same Σ durations."""
+        n = len(utterances)
+        arr = (Utterance * n)()
+        keep = []
+        for i, (ids, dur, noise) in enumerate(utterances):
+            u, k = self._utt(ids, dur, noise, noiseScale)
+            arr[i] = u
+            keep.append(k)
+        ns = int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(arr[0])))
+        self._keep[slot] = (keep, ns * n)
+        rc = self.lib.piper_hip_voice_prepare_batch(self.voice, arr, n, slot)
         if rc < 0:
             _check(rc)
         return rc

@@ -210,3 +210,35 @@ def test_time_subset_and_profile(rt_medium):
     # profiling replays non-idempotent steps; a normal launch afterwards must still be exact
     rt_medium.launch(10)
     assert np.array_equal(ref, rt_medium.collect(10))
+
+
+def test_batched_utterances_share_one_schedule(rt_medium, voices):
+    """N utterances of identical shape (same T, same Σ durations — ids, durations and noise all differ) run as ONE
+    schedule with a batch dimension; each waveform must match the oracle's for that utterance."""
+    cfg, blob = voices["medium"]
+    T, F = 28, 84
+    rng = np.random.RandomState(7)
+    utts = []
+    for b in range(4):
+        ids = list(rng.randint(0, 130, size=T))
+        dur = [3] * T
+        for _ in range(20):  # move frames around, keeping the total
+            i, j = rng.randint(0, T, size=2)
+            if dur[i] > 0:
+                dur[i] -= 1
+                dur[j] += 1
+        assert sum(dur) == F
+        utts.append((ids, dur, kd.sym(SD + 400 + b, (192, F), 1.7320508)))
+    utts[2] = (utts[2][0], utts[2][1], None)  # one item without injected noise
+    rt_medium.prepare_batch(11, utts, 0.667)
+    assert rt_medium.lib.piper_hip_voice_batch_size(rt_medium.voice, 11) == 4
+    rt_medium.launch(11)
+    audio = rt_medium.collect(11).reshape(4, F * 256)
+    for b, (ids, dur, noise) in enumerate(utts):
+        assert_close(audio[b], orc.synthesize(cfg, blob, ids, dur, noise, 0.667), WAVE_TOL, f"batch item {b}")
+    z = rt_medium.tap(11, "z", 4 * 192 * F).reshape(4, 192, F)
+    _, taps = orc.synthesize(cfg, blob, utts[1][0], utts[1][1], utts[1][2], 0.667, taps=True)
+    assert_close(z[1], taps["z"], OP_TOL, "z of batch item 1")
+    with pytest.raises(ph.ShapeMismatch):  # different Σ durations in one batch
+        rt_medium.prepare_batch(11, [utts[0], (utts[1][0], [3] * T, None)] if sum([3] * T) != F else
+                                [utts[0], (utts[1][0], [2] * T, None)], 0.667)
