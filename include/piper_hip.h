@@ -123,6 +123,20 @@ int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, const int6
                                   const piper_hip_convtranspose1d_params* p, float** out, int64_t out_shape[3],
                                   piper_hip_stream stream);
 
+/* bf16-operand variants of the two contractions (SURVEY.md §8b "bf16 variants", §8d config 5). The reference has no
+ * bf16 path, so these are a build extension with the SAME shapes, parameter structs and error behaviour as
+ * conv1dF32 / convTranspose1dF32 (MetalBackend.swift:1149-1228, 2812-2895): fp32 tensors in and out, x and w rounded
+ * to bf16 (nearest even) on the device, fp32 accumulation and bias on v_mfma_f32_32x32x16_bf16. Covered geometry:
+ * stride 1 (conv) / K % stride == 0 with pads (K−stride)/2 (convT), groups 1, C_in % 32 == 0 (convT: C_out too),
+ * padding and dilation reach ≤ 64; anything else returns PIPER_HIP_ERR_UNSUPPORTED so the caller can take the f32 op. */
+int piper_hip_conv1d_bf16(piper_hip_ctx* ctx, const float* input, const int64_t input_shape[3], const float* weight,
+                          const int64_t weight_shape[3], const float* bias, const piper_hip_conv1d_params* p, float** out,
+                          int64_t out_shape[3], piper_hip_stream stream);
+int piper_hip_convtranspose1d_bf16(piper_hip_ctx* ctx, const float* input, const int64_t input_shape[3],
+                                   const float* weight, const int64_t weight_shape[3], const float* bias,
+                                   const piper_hip_convtranspose1d_params* p, float** out, int64_t out_shape[3],
+                                   piper_hip_stream stream);
+
 /* MetalBackend.matmulF32 (MetalBackend.swift:1232-1323) → matmul_f32 (matmul.metal:22-49), with the
  * executor's rank-4 lead-dim broadcast (GraphExecutor.swift:1870-1899) done by stride-0 addressing
  * instead of a materialised expandF32.  Equal ranks ≥ 2 required (MetalBackend.swift:1236-1238);
@@ -266,6 +280,16 @@ int piper_hip_voice_synthetic_blob(const piper_hip_voice_config* cfg, uint64_t s
 int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_config* cfg, const float* blob, int on_device,
                            piper_hip_voice** out);
 void piper_hip_voice_destroy(piper_hip_voice* v);
+
+/* Arithmetic of the HiFi-GAN generator (94 % of the high voice's FLOPs). F32 (default): everything fp32, the parity
+ * configuration. BF16: every generator Conv / ConvTranspose takes bf16 operands (weights, and
+ * the LeakyReLU'd activations written by the producing conv) with fp32 accumulation; bias, residual stream, MRF mean,
+ * conv_post, the text encoder and the flow stay fp32. Stated tolerance: waveform SNR ≥ 35 dB against the fp32 result.
+ * Drops every prepared slot (prepare again). UNSUPPORTED when a generator conv is outside the bf16 kernels' geometry. */
+#define PIPER_HIP_PRECISION_F32 0
+#define PIPER_HIP_PRECISION_BF16 1
+int piper_hip_voice_set_precision(piper_hip_voice* v, int precision);
+int piper_hip_voice_precision(const piper_hip_voice* v);
 
 /* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104). The duration
  * predictor is outside this library's scope, so per-id frame counts are supplied (the reference's own

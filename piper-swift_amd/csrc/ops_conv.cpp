@@ -2,6 +2,7 @@
 // Shape contracts and error wording follow MetalBackend.conv1dF32 / convTranspose1dF32
 // (MetalBackend.swift:1149-1228, 2812-2895).
 #include "conv.h"
+#include "conv_bf16.h"
 
 using namespace ph;
 
@@ -117,6 +118,100 @@ PH_EXPORT int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, 
   }
   if (rc) return rc;
   return ss.finish("convtranspose1d_f32");
+}
+
+// bf16-operand variants (SURVEY.md §8b "bf16 variants", §8d config 5): same contract and shapes as the f32 entry points,
+// fp32 tensors in and out; x and w are rounded to bf16 (nearest even) on the device, products accumulate in fp32.
+// Geometry outside the bf16 kernels' coverage (stride ≠ 1, groups ≠ 1, Cin % 32 ≠ 0, padding > 64) → UNSUPPORTED.
+PH_EXPORT int piper_hip_conv1d_bf16(piper_hip_ctx* ctx, const float* x, const int64_t x_shape[3], const float* w,
+                                    const int64_t w_shape[3], const float* bias, const piper_hip_conv1d_params* p,
+                                    float** out, int64_t out_shape[3], piper_hip_stream stream) {
+  PH_CHECK_CTX(ctx);
+  if (!x_shape || !w_shape || !p) PH_FAIL(PIPER_HIP_ERR_ARG, "conv1dBF16: null shape/params");
+  const int64_t N = x_shape[0], Cin = x_shape[1], Lin = x_shape[2];
+  const int64_t Cout = w_shape[0], K = w_shape[2];
+  if (N < 0 || Cin < 0 || Lin < 0 || Cout < 0 || K <= 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv1dBF16: negative/zero dimension");
+  if (p->stride < 1 || p->dilation < 1 || p->pad_l < 0 || p->pad_r < 0)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv1dBF16: stride/dilation must be >=1 and pads >=0");
+  if (w_shape[1] != Cin) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv1dBF16 weight C_in mismatch: weight[1]=%lld input C=%lld", (long long)w_shape[1], (long long)Cin);
+  if (p->stride != 1 || (p->groups > 1) || !conv_bf16_eligible((int)Cout, (int)Cin, (int)K, p->dilation, p->pad_l, p->pad_r))
+    PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv1dBF16: geometry not covered (stride 1, groups 1, C_in %% 32 == 0, padding <= 64)");
+  const int64_t Lout = Lin + p->pad_l + p->pad_r - (int64_t)p->dilation * (K - 1);
+  if (Lout < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv1dBF16 produced invalid L_out=%lld", (long long)Lout);
+  if (out_shape) { out_shape[0] = N; out_shape[1] = Cout; out_shape[2] = Lout; }
+  const int64_t count = N * Cout * Lout;
+  if (!fits_i32(Cin * Lin) || !fits_i32(Cout * Lout) || !fits_i32(Cin * K * Cout))
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv1dBF16: tensor too large for 32-bit indexing");
+  int rc = ensure_out(ctx, out, (size_t)count, 0);
+  if (rc) return rc;
+  if (count == 0) return PIPER_HIP_OK;
+  if (!x || !w) PH_FAIL(PIPER_HIP_ERR_ARG, "conv1dBF16: null input");
+  StreamScope ss(ctx, stream);
+  const int64_t Lmax = Lin > Lout ? Lin : Lout;
+  const int64_t row = c8_row_len(Lmax);
+  const size_t img_bytes = (size_t)N * (Cin / 8) * row * 16;
+  void *img = nullptr, *pw = nullptr;
+  rc = ctx->pool.alloc(img_bytes, &img);
+  if (rc) return rc;
+  defer_free(ctx, img);
+  rc = ctx->pool.alloc(packed_conv_bf16_elems((int)Cout, (int)Cin, (int)K) * 2, &pw);
+  if (rc) return rc;
+  defer_free(ctx, pw);
+  PH_HIP(hipMemsetAsync(img, 0, img_bytes, ss.s), PIPER_HIP_ERR_LAUNCH);
+  pack_act_c8(ss.s, x, (int)N, (int)Cin, (int)Lin, 1.0f, (uint16_t*)img, row);
+  pack_conv_weights_bf16(ss.s, w, (int)Cout, (int)Cin, (int)K, (uint16_t*)pw);
+  ConvBf16Args a;
+  a.x = (const uint16_t*)img; a.w = (const uint16_t*)pw; a.bias = bias; a.y = *out;
+  a.N = (int)N; a.Cin = (int)Cin; a.Cout = (int)Cout; a.K = (int)K; a.dil = p->dilation; a.padL = p->pad_l;
+  a.Lout = (int)Lout; a.x_row = (int)row; a.y_len = (int)Lout;
+  rc = launch_conv_bf16(ctx, ss.s, a);
+  if (rc) return rc;
+  return ss.finish("conv1d_bf16");
+}
+
+PH_EXPORT int piper_hip_convtranspose1d_bf16(piper_hip_ctx* ctx, const float* x, const int64_t x_shape[3], const float* w,
+                                             const int64_t w_shape[3], const float* bias,
+                                             const piper_hip_convtranspose1d_params* p, float** out, int64_t out_shape[3],
+                                             piper_hip_stream stream) {
+  PH_CHECK_CTX(ctx);
+  if (!x_shape || !w_shape || !p) PH_FAIL(PIPER_HIP_ERR_ARG, "convTranspose1dBF16: null shape/params");
+  const int64_t N = x_shape[0], Cin = x_shape[1], Lin = x_shape[2];
+  if (N < 0 || Cin < 0 || Lin < 0 || w_shape[1] < 0 || w_shape[2] <= 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "convTranspose1dBF16: bad dimension");
+  if (p->stride < 1 || p->dilation < 1 || p->pad_l < 0 || p->pad_r < 0 || p->output_padding < 0)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "convTranspose1dBF16: stride/dilation must be >=1 and pads >=0");
+  if (w_shape[0] != Cin) PH_FAIL(PIPER_HIP_ERR_SHAPE, "convTranspose1dBF16 weight[0] mismatch: %lld vs C_in=%lld", (long long)w_shape[0], (long long)Cin);
+  const int64_t Cout = w_shape[1], K = w_shape[2];
+  if (p->groups > 1 || !convt_bf16_eligible((int)Cin, (int)Cout, (int)K, p->stride, p->pad_l, p->pad_r, p->dilation, p->output_padding))
+    PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "convTranspose1dBF16: geometry not covered (groups 1, dilation 1, C_in,C_out %% 32 == 0, K %% stride == 0, pads = (K-stride)/2)");
+  const int64_t Lout = Lin * p->stride;  // (L−1)s − 2·pad + K with K − s = 2·pad
+  if (out_shape) { out_shape[0] = N; out_shape[1] = Cout; out_shape[2] = Lout; }
+  const int64_t count = N * Cout * Lout;
+  if (!fits_i32(Cin * Lin) || !fits_i32(Cout * Lout) || !fits_i32(Cin * Cout * K))
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "convTranspose1dBF16: tensor too large for 32-bit indexing");
+  int rc = ensure_out(ctx, out, (size_t)count, 0);
+  if (rc) return rc;
+  if (count == 0) return PIPER_HIP_OK;
+  if (!x || !w) PH_FAIL(PIPER_HIP_ERR_ARG, "convTranspose1dBF16: null input");
+  StreamScope ss(ctx, stream);
+  const int64_t row = c8_row_len(Lin);
+  const size_t img_bytes = (size_t)N * (Cin / 8) * row * 16;
+  void *img = nullptr, *pw = nullptr;
+  rc = ctx->pool.alloc(img_bytes, &img);
+  if (rc) return rc;
+  defer_free(ctx, img);
+  rc = ctx->pool.alloc(packed_convt_bf16_elems((int)Cin, (int)Cout, (int)K, p->stride) * 2, &pw);
+  if (rc) return rc;
+  defer_free(ctx, pw);
+  PH_HIP(hipMemsetAsync(img, 0, img_bytes, ss.s), PIPER_HIP_ERR_LAUNCH);
+  pack_act_c8(ss.s, x, (int)N, (int)Cin, (int)Lin, 1.0f, (uint16_t*)img, row);
+  pack_convt_weights_bf16(ss.s, w, (int)Cin, (int)Cout, (int)K, p->stride, p->pad_l, (uint16_t*)pw);
+  ConvBf16Args a;
+  a.x = (const uint16_t*)img; a.w = (const uint16_t*)pw; a.bias = bias; a.y = *out;
+  a.N = (int)N; a.Cin = (int)Cin; a.Cout = (int)Cout; a.K = (int)K; a.Lout = (int)Lin; a.x_row = (int)row; a.y_len = (int)Lout;
+  a.ct_stride = p->stride; a.ct_pad = p->pad_l;
+  rc = launch_conv_bf16(ctx, ss.s, a);
+  if (rc) return rc;
+  return ss.finish("convtranspose1d_bf16");
 }
 
 PH_EXPORT int piper_hip_wavenet_layer_f32(piper_hip_ctx* ctx, const float* x, const float* skip_in, const float* w_in,

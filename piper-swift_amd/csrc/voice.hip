@@ -19,6 +19,7 @@
 
 #include "../../include/piper_hip_voice_layout.h"
 #include "conv.h"
+#include "conv_bf16.h"
 
 namespace ph {
 int validate_config(const piper_hip_voice_config* c);
@@ -191,6 +192,16 @@ struct piper_hip_voice {
     std::vector<std::vector<ConvW>> rb;  // [n_rb][n_dil or 2·n_dil]
   };
   std::vector<Stage> stages;
+  // bf16 generator (PIPER_HIP_PRECISION_BF16): fragment images of the same decoder convs, built by set_precision
+  struct ConvWB {
+    const uint16_t* w = nullptr;
+    const float* bias = nullptr;
+    int Cout = 0, Cin = 0, K = 0;
+  };
+  int precision = PIPER_HIP_PRECISION_F32;
+  ConvWB conv_pre_b;
+  std::vector<ConvWB> up_b;                             // [stage]
+  std::vector<std::vector<std::vector<ConvWB>>> rb_b;   // [stage][rb][conv]
   std::vector<void*> owned;
   Slot slots[kMaxSlots];
   int hop = 1;
@@ -400,6 +411,142 @@ void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW&
   s.steps.push_back(std::move(st));
 }
 
+// conv step over a bf16 fragment image
+void add_conv_bf16(piper_hip_voice* v, Slot& s, const std::string& name, const piper_hip_voice::ConvWB& w, ConvBf16Args a,
+                   double flops) {
+  a.w = w.w; a.bias = w.bias; a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K;
+  piper_hip_ctx* ctx = v->ctx;
+  Step st;
+  st.name = name;
+  st.run = [ctx, a](hipStream_t q) { return launch_conv_bf16(ctx, q, a); };
+  st.flops = flops;
+  const double cols = (double)a.N * a.Lout, out_cols = a.ct_stride > 0 ? cols * a.ct_stride : cols;
+  st.bytes = 2.0 * (w.Cin * cols + (double)w.Cout * w.Cin * w.K) + (a.act ? 2.0 : 0.0) * w.Cout * out_cols +
+             ((a.y ? 4.0 : 0.0) + (a.res ? 4.0 : 0.0) + (a.mrf_a ? 8.0 : 0.0)) * w.Cout * out_cols;
+  st.lane = 0;
+  st.tag = "conv_bf16";
+  s.steps.push_back(std::move(st));
+}
+
+// HiFi-GAN generator with bf16 contraction operands. Same graph as the fp32 generator below;
+// what changes is the data each conv READS: the C8 bf16 image of LeakyReLU(x) written by its producer's epilogue
+// (conv_bf16.h). The residual stream, the bias adds and the MRF mean stay fp32, so rounding enters only through the
+// operands of each contraction and does not accumulate along the residual chain.
+int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z, float* dec0, int F, int NB) {
+  const piper_hip_voice_config& c = v->cfg;
+  const int I = c.inter;
+  const size_t B = (size_t)NB;
+  hipStream_t zs = s.stream;
+  auto image = [&](int C, int L) -> uint16_t* {  // zeroed once per build: kernels write the interior only
+    const size_t bytes = (size_t)c8_elems(NB, C, L) * 2;
+    void* p = ar.raw(bytes);
+    if (p && hipMemsetAsync(p, 0, bytes, zs) != hipSuccess) ar.rc = PIPER_HIP_ERR_LAUNCH;
+    return (uint16_t*)p;
+  };
+  uint16_t* zc8 = image(I, F);
+  uint16_t* a_in = image(c.up_initial, F);
+  if (ar.rc) return ar.rc;
+  {
+    Step st;
+    st.name = "dec.z_to_bf16";
+    st.run = [=](hipStream_t q) { return pack_act_c8(q, z, NB, I, F, 1.0f, zc8); };
+    s.steps.push_back(st);
+  }
+  {
+    ConvBf16Args a;
+    a.x = zc8; a.y = dec0; a.act = a_in; a.act_alpha = 0.1f;  // the first stage's ConvTranspose reads lrelu(conv_pre)
+    a.N = NB; a.dil = 1; a.padL = 3; a.Lout = F; a.x_row = (int)c8_row_len(F); a.act_row = (int)c8_row_len(F); a.y_len = F;
+    add_conv_bf16(v, s, "dec.conv_pre", v->conv_pre_b, a, NB * conv_flops(c.up_initial, I, 7, F));
+  }
+  s.taps["dec_pre"] = {dec0, B * c.up_initial * F};
+  int L = F;
+  const float* mean = nullptr;
+  for (int u = 0; u < c.n_ups; u++) {
+    const auto& S = v->stages[u];
+    const bool last_stage = u + 1 == c.n_ups;
+    const int Lo = L * S.stride;
+    const int row = (int)c8_row_len(Lo);
+    float* up = ar.f32(B * S.Cout * Lo);
+    uint16_t* a_up = image(S.Cout, Lo);
+    uint16_t* a_next = last_stage ? nullptr : image(S.Cout, Lo);  // lrelu(MRF mean): the next stage's input
+    float* m = last_stage ? ar.f32(B * S.Cout * Lo) : nullptr;    // conv_post reads the fp32 mean
+    float* r[PIPER_HIP_MAX_RB];
+    float* tmp[PIPER_HIP_MAX_RB][2];
+    uint16_t* act[PIPER_HIP_MAX_RB][2];
+    uint16_t* mid[PIPER_HIP_MAX_RB];
+    for (int j = 0; j < c.n_rb; j++) {
+      r[j] = ar.f32(B * S.Cout * Lo);
+      for (int i = 0; i < 2; i++) {
+        tmp[j][i] = ar.f32(B * S.Cout * Lo);
+        act[j][i] = image(S.Cout, Lo);
+      }
+      mid[j] = c.resblock_type == 1 ? image(S.Cout, Lo) : nullptr;
+    }
+    if (ar.rc) return ar.rc;
+    const std::string p = "dec.s" + std::to_string(u) + ".";
+    {
+      ConvBf16Args a;
+      a.x = a_in; a.y = up; a.act = a_up; a.act_alpha = 0.1f;
+      a.N = NB; a.Lout = L; a.x_row = (int)c8_row_len(L); a.act_row = row; a.y_len = Lo;
+      a.ct_stride = S.stride; a.ct_pad = S.pad;
+      add_conv_bf16(v, s, p + "lrelu_convT", v->up_b[u], a, NB * 2.0 * S.Cin * S.Cout * (double)S.K * L);
+    }
+    for (int j = 0; j < c.n_rb; j++) {
+      const int K = c.rb_kernels[j];
+      const float* src = up;
+      const uint16_t* src_act = a_up;
+      for (int di = 0; di < c.rb_n_dil; di++) {
+        const int dil = c.rb_dilations[j][di];
+        const bool lastd = di + 1 == c.rb_n_dil;
+        const bool fuse_mean = lastd && j + 1 == c.n_rb;  // r0, r1 are complete: fold (r0+r1+r2)/3 into this epilogue
+        float* dst = lastd ? (fuse_mean ? m : r[j]) : tmp[j][di & 1];
+        uint16_t* dst_act = lastd ? (fuse_mean ? a_next : nullptr) : act[j][di & 1];
+        const std::string nm = p + "rb" + std::to_string(j) + ".c" + std::to_string(di);
+        auto rbconv = [&](const uint16_t* in, int dl) {
+          ConvBf16Args a;
+          a.x = in; a.N = NB; a.dil = dl; a.padL = (K * dl - dl) / 2; a.Lout = Lo; a.x_row = row; a.act_row = row; a.y_len = Lo;
+          a.act_alpha = 0.1f;
+          return a;
+        };
+        auto finish = [&](ConvBf16Args a) {  // the conv that closes the residual: x ← x + conv(…)
+          a.res = src; a.y = dst; a.act = dst_act;
+          if (fuse_mean) { a.mrf_a = r[0]; a.mrf_b = r[1]; }
+          return a;
+        };
+        const double fl = NB * conv_flops(S.Cout, S.Cout, K, Lo);
+        if (c.resblock_type == 1) {
+          ConvBf16Args a1 = rbconv(src_act, dil);
+          a1.act = mid[j];
+          add_conv_bf16(v, s, nm + "a_lrelu_conv", v->rb_b[u][j][2 * di], a1, fl);
+          add_conv_bf16(v, s, nm + (fuse_mean ? "b_lrelu_conv_res_mrfmean" : "b_lrelu_conv_res"), v->rb_b[u][j][2 * di + 1],
+                        finish(rbconv(mid[j], 1)), fl);
+        } else {
+          add_conv_bf16(v, s, nm + (fuse_mean ? "_lrelu_conv_res_mrfmean" : "_lrelu_conv_res"), v->rb_b[u][j][di],
+                        finish(rbconv(src_act, dil)), fl);
+        }
+        src = dst;
+        src_act = dst_act;
+      }
+    }
+    a_in = a_next;
+    mean = m;
+    L = Lo;
+  }
+  s.n_samples = L;
+  s.audio = ar.f32(B * L);
+  if (ar.rc) return ar.rc;
+  {
+    ConvArgs a;  // 32→1 k7: thread-per-output fp32 kernel on the fp32 mean, LeakyReLU(0.01) as its prologue
+    a.x = mean;
+    a.prologue = PRO_LRELU; a.alpha = 0.01f;
+    a.y = s.audio; a.N = NB; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
+    a.epilogue = EPI_TANH;
+    add_conv(v, s, "dec.conv_post_tanh", v->conv_post, a, L);
+  }
+  return PIPER_HIP_OK;
+}
+
 int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   const piper_hip_voice_config& c = v->cfg;
   piper_hip_ctx* ctx = v->ctx;
@@ -564,6 +711,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
     z = zflip;
   }
   s.taps["z"] = {z, B * I * F};
+  if (v->precision == PIPER_HIP_PRECISION_BF16) return build_generator_bf16(v, s, ar, z, dec0, F, NB);
   // ---------------- HiFi-GAN generator
   {
     ConvArgs a = plain(z, dec0, I, c.up_initial, F);
@@ -797,6 +945,90 @@ PH_EXPORT int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_c
   *out = v.release();
   return PIPER_HIP_OK;
 }
+
+PH_EXPORT int piper_hip_voice_set_precision(piper_hip_voice* v, int precision) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  if (precision != PIPER_HIP_PRECISION_F32 && precision != PIPER_HIP_PRECISION_BF16)
+    PH_FAIL(PIPER_HIP_ERR_ARG, "voice_set_precision: unknown precision %d", precision);
+  if (precision == v->precision) return PIPER_HIP_OK;
+  piper_hip_ctx* ctx = v->ctx;
+  const piper_hip_voice_config& c = v->cfg;
+  PH_HIP(hipSetDevice(ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);
+  if (precision == PIPER_HIP_PRECISION_BF16 && v->up_b.empty()) {
+    // every generator conv must fall inside the bf16 kernels' geometry; otherwise the voice stays fp32
+    if (!conv_bf16_eligible(c.up_initial, c.inter, 7, 1, 3, 3))
+      PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "bf16 generator: conv_pre %d→%d not covered", c.inter, c.up_initial);
+    size_t elems = packed_conv_bf16_elems(c.up_initial, c.inter, 7);
+    for (const auto& S : v->stages) {
+      if (!convt_bf16_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, S.pad, 1, 0))
+        PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "bf16 generator: ConvTranspose %d→%d k%d s%d not covered", S.Cin, S.Cout, S.K, S.stride);
+      elems += packed_convt_bf16_elems(S.Cin, S.Cout, S.K, S.stride);
+      for (int j = 0; j < c.n_rb; j++)
+        for (int di = 0; di < c.rb_n_dil; di++) {
+          const int K = c.rb_kernels[j], dl = c.rb_dilations[j][di], pad = (K * dl - dl) / 2;
+          if (!conv_bf16_eligible(S.Cout, S.Cout, K, dl, pad, pad))
+            PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "bf16 generator: ResBlock conv C=%d k%d d%d not covered", S.Cout, K, dl);
+          elems += (c.resblock_type == 1 ? 2 : 1) * packed_conv_bf16_elems(S.Cout, S.Cout, K);
+        }
+    }
+    void* p = nullptr;
+    int rc = ctx->pool.alloc(elems * 2 + 256 * (size_t)(2 + c.n_ups * (1 + c.n_rb * c.rb_n_dil * 2)), &p);
+    if (rc) return rc;
+    v->owned.push_back(p);
+    uint16_t* cur = (uint16_t*)p;
+    hipStream_t q = ctx->default_stream;
+    auto take = [&](size_t n) { uint16_t* r = cur; cur += (n + 127) & ~(size_t)127; return r; };
+    auto conv = [&](const std::string& prefix, int Cout, int Cin, int K) {
+      piper_hip_voice::ConvWB w;
+      w.Cout = Cout; w.Cin = Cin; w.K = K;
+      uint16_t* img = take(packed_conv_bf16_elems(Cout, Cin, K));
+      pack_conv_weights_bf16(q, tensor(v, prefix + ".weight"), Cout, Cin, K, img);
+      w.w = img;
+      w.bias = tensor(v, prefix + ".bias");
+      return w;
+    };
+    v->conv_pre_b = conv("dec.conv_pre", c.up_initial, c.inter, 7);
+    char nm[128];
+    for (int u = 0; u < c.n_ups; u++) {
+      const auto& S = v->stages[u];
+      piper_hip_voice::ConvWB w;
+      w.Cout = S.Cout; w.Cin = S.Cin; w.K = S.K;
+      uint16_t* img = take(packed_convt_bf16_elems(S.Cin, S.Cout, S.K, S.stride));
+      snprintf(nm, sizeof nm, "dec.ups.%d", u);
+      pack_convt_weights_bf16(q, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, S.pad, img);
+      w.w = img;
+      w.bias = tensor(v, std::string(nm) + ".bias");
+      v->up_b.push_back(w);
+      std::vector<std::vector<piper_hip_voice::ConvWB>> rbs;
+      for (int j = 0; j < c.n_rb; j++) {
+        std::vector<piper_hip_voice::ConvWB> convs;
+        const int rb = u * c.n_rb + j;
+        for (int di = 0; di < c.rb_n_dil; di++) {
+          if (c.resblock_type == 1) {
+            snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", rb, di);
+            convs.push_back(conv(nm, S.Cout, S.Cout, c.rb_kernels[j]));
+            snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", rb, di);
+            convs.push_back(conv(nm, S.Cout, S.Cout, c.rb_kernels[j]));
+          } else {
+            snprintf(nm, sizeof nm, "dec.resblocks.%d.convs.%d", rb, di);
+            convs.push_back(conv(nm, S.Cout, S.Cout, c.rb_kernels[j]));
+          }
+        }
+        rbs.push_back(convs);
+      }
+      v->rb_b.push_back(rbs);
+    }
+    hipError_t e = hipStreamSynchronize(q);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_set_precision: packing failed: %s", hipGetErrorString(e));
+  }
+  for (auto& s : v->slots) slot_release(v, s, false);  // schedules are rebuilt by the next prepare
+  v->precision = precision;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_precision(const piper_hip_voice* v) { return v ? v->precision : -1; }
 
 PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
   if (!v) return;

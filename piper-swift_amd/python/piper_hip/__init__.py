@@ -122,6 +122,10 @@ _PROTOS = {
                                        C.POINTER(c_vp), c_i64p, c_vp]),
     "piper_hip_convtranspose1d_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, c_vp,
                                                 C.POINTER(ConvTranspose1dParams), C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_conv1d_bf16": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, c_vp, C.POINTER(Conv1dParams),
+                                        C.POINTER(c_vp), c_i64p, c_vp]),
+    "piper_hip_convtranspose1d_bf16": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, c_vp,
+                                                 C.POINTER(ConvTranspose1dParams), C.POINTER(c_vp), c_i64p, c_vp]),
     "piper_hip_matmul_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_i64p, c_vp]),
     "piper_hip_softmax_lastdim_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
     "piper_hip_unary_f32": (C.c_int, [c_vp, C.c_int, c_vp, C.c_size_t, C.c_float, C.POINTER(c_vp), c_vp]),
@@ -151,6 +155,8 @@ _PROTOS = {
                                               C.POINTER(C.c_int)]),
     "piper_hip_voice_synthetic_blob": (C.c_int, [C.POINTER(VoiceConfig), C.c_uint64, c_f32p, C.c_size_t]),
     "piper_hip_voice_create": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_vp, C.c_int, C.POINTER(c_vp)]),
+    "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
+    "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
     "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
     "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
@@ -325,6 +331,32 @@ class HipBackend:
         _check(self.lib.piper_hip_convtranspose1d_f32(self.ctx, _ptr(input), _i64(inputShape), _ptr(weight),
                                                       _i64(weightShape), _ptr(bias), C.byref(prm), C.byref(p), osh,
                                                       commandBuffer))
+        return self._out(p, list(osh))
+
+    def conv1dBF16(self, input, inputShape, weight, weightShape, bias, stride=1, dilation=1, padL=0, padR=0, groups=1,
+                   commandBuffer=None):
+        """conv1dF32's contract with bf16 operands / fp32 accumulation (build extension; UnsupportedOp outside its geometry)."""
+        if len(inputShape) != 3:
+            raise ShapeMismatch("conv1dBF16 input must be [N,C,L]")
+        if len(weightShape) != 3:
+            raise ShapeMismatch("conv1dBF16 weight must be [C_out,C_in,K]")
+        prm = Conv1dParams(stride, dilation, padL, padR, groups)
+        p, osh = c_vp(), (C.c_int64 * 3)()
+        _check(self.lib.piper_hip_conv1d_bf16(self.ctx, _ptr(input), _i64(inputShape), _ptr(weight), _i64(weightShape),
+                                              _ptr(bias), C.byref(prm), C.byref(p), osh, commandBuffer))
+        return self._out(p, list(osh))
+
+    def convTranspose1dBF16(self, input, inputShape, weight, weightShape, bias, stride=1, dilation=1, padL=0, padR=0,
+                            outputPadding=0, groups=1, commandBuffer=None):
+        if len(inputShape) != 3:
+            raise ShapeMismatch("convTranspose1dBF16 input must be [N,C,L]")
+        if len(weightShape) != 3:
+            raise ShapeMismatch("convTranspose1dBF16 weight must be [C_in,C_out,K]")
+        prm = ConvTranspose1dParams(stride, dilation, padL, padR, outputPadding, groups)
+        p, osh = c_vp(), (C.c_int64 * 3)()
+        _check(self.lib.piper_hip_convtranspose1d_bf16(self.ctx, _ptr(input), _i64(inputShape), _ptr(weight),
+                                                       _i64(weightShape), _ptr(bias), C.byref(prm), C.byref(p), osh,
+                                                       commandBuffer))
         return self._out(p, list(osh))
 
     def matmulF32(self, a, aShape, b, bShape, commandBuffer=None):
@@ -514,6 +546,12 @@ class HipRuntime:
         if self.voice:
             self.lib.piper_hip_voice_destroy(self.voice)
             self.voice = None
+
+    def set_precision(self, precision):
+        """"f32" (default, the parity configuration) or "bf16" (generator convs on bf16 operands, fp32 accumulate)."""
+        code = {"f32": 0, "fp32": 0, "bf16": 1}.get(precision, precision)
+        _check(self.lib.piper_hip_voice_set_precision(self.voice, int(code)))
+        self._keep.clear()  # prepared slots are dropped by the library
 
     def _utt(self, ids, durations, noise, noise_scale):
         ids = np.ascontiguousarray(ids, np.int64)

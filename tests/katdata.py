@@ -177,3 +177,30 @@ def unary_input():
 
 
 FIXTURE_IDS = [1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2]  # bench/fixtures/test_summary.json:8
+
+
+def bf16_round(a):
+    """fp32 → nearest-even bf16 → fp32 (what v_cvt_pk_bf16_f32 does; no NaN/Inf in the test data)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+# bf16-operand conv cases: (Cin, Cout, K, dil, padL, padR, L, N, bias)
+CONV_BF16_CASES = [
+    (32, 32, 7, 1, 3, 3, 200, 1, True),       # last decoder stage / conv_post-like reach
+    (64, 64, 3, 5, 5, 5, 1000, 2, True),      # ResBlock1 dilation 5, batch 2
+    (192, 256, 7, 1, 3, 3, 42, 1, True),      # conv_pre medium at factor 1
+    (256, 256, 11, 5, 25, 25, 300, 1, True),  # widest reach of the high voice
+    (128, 128, 7, 12, 36, 36, 2688, 1, True), # widest reach of the medium voice, stage 0 at factor 8
+    (32, 40, 3, 1, 0, 2, 77, 1, False),       # ragged: Cout not a multiple of 32, asymmetric pads, no bias
+    (96, 64, 1, 1, 0, 0, 130, 3, True),       # k=1, 3 row groups of channels, batch 3
+    (32, 32, 5, 2, 4, 4, 5, 1, True),         # row shorter than the reach
+]
+# (Cin, Cout, K, stride, L, N)
+CONVT_BF16_CASES = [
+    (256, 128, 16, 8, 42, 1),
+    (64, 32, 8, 4, 500, 2),
+    (128, 64, 4, 2, 129, 1),
+    (512, 256, 16, 8, 20, 1),
+]

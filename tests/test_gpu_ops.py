@@ -10,6 +10,8 @@ import piper_hip as ph
 from conftest import OP_TOL, assert_close, subsample_like
 from test_oracle_golden import rb_inputs, wn_inputs
 
+SD = 1234 + 600011  # seeds of the bf16 cases (disjoint from katdata.case_seed ranges)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -331,3 +333,50 @@ def test_convtranspose1d_bulk(case, backend):
     out, shp = backend.convTranspose1dF32(up(backend, x), list(x.shape), up(backend, w), list(w.shape), up(backend, b), stride=s,
                                           padL=pad, padR=pad)
     assert_close(dl(backend, out, shp), orc.convtranspose1d(x, w, b, s, 1, pad, pad, 0, 1), OP_TOL)
+
+
+# ---- bf16-operand variants. Checker: the fp32 oracle on operands rounded to bf16 on the
+# host — products of two bf16 values are exact in fp32, so only the accumulation order differs (OP_TOL).
+@pytest.mark.parametrize("idx", range(len(kd.CONV_BF16_CASES)))
+def test_conv1d_bf16(idx, backend):
+    Cin, Cout, K, d, pl, pr, L, N, has_b = kd.CONV_BF16_CASES[idx]
+    x = kd.sym(SD + 900 + idx, (N, Cin, L))
+    w = kd.weight(SD + 950 + idx, (Cout, Cin, K), Cin * K)
+    b = kd.sym(SD + 990 + idx, (Cout,), 0.1) if has_b else None
+    out, shp = backend.conv1dBF16(up(backend, x), list(x.shape), up(backend, w), list(w.shape),
+                                  None if b is None else up(backend, b), dilation=d, padL=pl, padR=pr)
+    ref = orc.conv1d(kd.bf16_round(x), kd.bf16_round(w), b, 1, d, pl, pr)
+    assert shp == list(ref.shape)
+    assert_close(dl(backend, out, shp), ref, OP_TOL, f"conv1d_bf16 case {idx}")
+    # and it IS a bf16 computation: the unrounded fp32 result differs by about 2^-9 relative
+    full = orc.conv1d(x, w, b, 1, d, pl, pr)
+    err = np.abs(ref - full).max() / max(1.0, np.abs(full).max())
+    assert err < 2e-2
+
+
+@pytest.mark.parametrize("idx", range(len(kd.CONVT_BF16_CASES)))
+def test_convtranspose1d_bf16(idx, backend):
+    Cin, Cout, K, s, L, N = kd.CONVT_BF16_CASES[idx]
+    pad = (K - s) // 2
+    x = kd.sym(SD + 1000 + idx, (N, Cin, L))
+    w = kd.weight(SD + 1050 + idx, (Cin, Cout, K), Cin * K // s)
+    b = kd.sym(SD + 1090 + idx, (Cout,), 0.1)
+    out, shp = backend.convTranspose1dBF16(up(backend, x), list(x.shape), up(backend, w), list(w.shape), up(backend, b),
+                                           stride=s, padL=pad, padR=pad)
+    ref = orc.convtranspose1d(kd.bf16_round(x), kd.bf16_round(w), b, s, 1, pad, pad)
+    assert shp == list(ref.shape)
+    assert_close(dl(backend, out, shp), ref, OP_TOL, f"convT_bf16 case {idx}")
+
+
+def test_bf16_variants_refuse_uncovered_geometry(backend):
+    x = up(backend, np.zeros((1, 32, 16), np.float32))
+    w = up(backend, np.zeros((32, 32, 3), np.float32))
+    with pytest.raises(ph.UnsupportedOp):
+        backend.conv1dBF16(x, [1, 32, 16], w, [32, 32, 3], None, stride=2)
+    with pytest.raises(ph.UnsupportedOp):
+        backend.conv1dBF16(up(backend, np.zeros((1, 20, 16), np.float32)), [1, 20, 16],
+                           up(backend, np.zeros((8, 20, 3), np.float32)), [8, 20, 3], None)
+    with pytest.raises(ph.UnsupportedOp):
+        backend.convTranspose1dBF16(x, [1, 32, 16], w, [32, 32, 3], None, stride=2)  # K % stride != 0
+    with pytest.raises(ph.ShapeMismatch):
+        backend.conv1dBF16(x, [1, 32, 16], w, [32, 16, 3], None)

@@ -242,3 +242,48 @@ def test_batched_utterances_share_one_schedule(rt_medium, voices):
     with pytest.raises(ph.ShapeMismatch):  # different Σ durations in one batch
         rt_medium.prepare_batch(11, [utts[0], (utts[1][0], [3] * T, None)] if sum([3] * T) != F else
                                 [utts[0], (utts[1][0], [2] * T, None)], 0.667)
+
+
+def snr_db(x, ref):
+    x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+    return 10.0 * np.log10((ref ** 2).sum() / max(((x - ref) ** 2).sum(), 1e-300))
+
+
+BF16_MIN_SNR_DB = 35.0  # stated tolerance of the bf16 generator: waveform SNR vs the fp32 result
+
+
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_bf16_generator_snr(quality, voices, backend):
+    """PIPER_HIP_PRECISION_BF16: generator convs on bf16 operands, fp32 accumulate / residual stream (config 5).
+    Checked against the fp32 ORACLE waveform (not against our own fp32 path)."""
+    cfg, blob = voices[quality]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        ids, dur = kd.FIXTURE_IDS * 2, [3] * 28
+        F = sum(dur)
+        noise = kd.sym(SD + 500, (cfg.inter, F), 1.7320508)
+        ref = orc.synthesize(cfg, blob, ids, dur, noise, 0.667)
+        fp32 = rt.synthesize(ids, dur, noise, 0.667)
+        rt.set_precision("bf16")
+        assert rt.lib.piper_hip_voice_precision(rt.voice) == 1
+        rt.prepare(0, ids, dur, noise, 0.667)
+        rt.launch(0)
+        bf = rt.collect(0)
+        # encoder + flow are untouched by the precision switch: z is still the fp32 result
+        _, taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+        assert_close(rt.tap(0, "z", cfg.inter * F), taps["z"].reshape(-1), OP_TOL, "z under bf16 precision")
+        s = snr_db(bf, ref)
+        print(f"{quality}: bf16 generator SNR vs fp32 oracle = {s:.1f} dB; max|Δ| = {np.abs(bf - ref).max():.3e}")
+        assert s >= BF16_MIN_SNR_DB, s
+        assert not np.array_equal(bf, fp32)  # it really is a different arithmetic
+        # batch of 2 through the bf16 schedule
+        rt.prepare_batch(1, [(ids, dur, noise), (ids[::-1], dur, None)], 0.667)
+        rt.launch(1)
+        both = rt.collect(1).reshape(2, -1)
+        assert snr_db(both[0], ref) >= BF16_MIN_SNR_DB
+        assert snr_db(both[1], orc.synthesize(cfg, blob, ids[::-1], dur, None, 0.667)) >= BF16_MIN_SNR_DB
+        # and back: the fp32 path is bit-identical to what it produced before the switch
+        rt.set_precision("f32")
+        assert np.array_equal(rt.synthesize(ids, dur, noise, 0.667), fp32)
+    finally:
+        rt.close()
