@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 FIXTURE_IDS = [1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2]  # bench/fixtures/test_summary.json:8
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -54,6 +55,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--factor", type=int, default=8)
     ap.add_argument("--quality", default="medium", choices=["medium", "high"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="bf16 = BASELINE configs[4]: generator convs on bf16 operands with fp32 accumulate (use with --quality high)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-bench", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -116,6 +119,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    bf16 = args.precision == "bf16"
+    if bf16:
+        rt.set_precision("bf16")
     hop, sr = cfg.hop, cfg.sample_rate
     ids, dur, noise = utterance(args.factor, 1234 + rank, cfg.inter)
     n_samples = rt.num_samples(ids, dur)
@@ -154,7 +160,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic (seeded weights of Piper-medium geometry, fixture phoneme ids tiled, pinned 3 frames/id, injected noise)",
         "config": {"workload": f"{args.quality} factor={args.factor}: {len(ids)} ids, {sum(dur)} frames, {n_samples} samples "
                                f"({audio_sec:.3f} s audio) per utterance, 1 utterance per step per GPU",
@@ -178,20 +184,23 @@ def main():
             tot_us = sum(s["avg_us"] for s in stats)
             # the dominant kernel timed the way it runs in production: its 87 launches replayed as their own HIP graph
             # between two events on the slot stream (kernel time + dispatch boundary, no per-kernel event overhead)
-            avg_us, n_l, m_fl, m_by = rt.time_subset(0, "conv_mfma", iters=30)
+            avg_us, n_l, m_fl, m_by = rt.time_subset(0, "conv_bf16" if bf16 else "conv_mfma", iters=30)
             m_us = avg_us * n_l
+            peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
             achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0
             traffic = None
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "r1_rocprof_summary.json")))
-                if args.factor == 8 and args.quality == "medium":
+                if args.factor == 8 and args.quality == "medium" and not bf16:
                     traffic = pj["traffic"]["conv_stream_kernel"]["hbm_mb_per_launch"] * 1e6
             except Exception:
                 pass
             out["roofline"] = {
-                "kernel": "conv_stream_kernel (fp32 MFMA implicit-GEMM Conv1d/ConvTranspose1d; all of its launches in one utterance)",
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "kernel": ("conv_bf16_kernel (bf16-operand MFMA Conv1d/ConvTranspose1d of the generator, LDS-resident input window; all of its launches in one utterance)"
+                           if bf16 else
+                           "conv_stream_kernel (fp32 MFMA implicit-GEMM Conv1d/ConvTranspose1d; all of its launches in one utterance)"),
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per launch from profiles/r1_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; algorithmic bytes per launch "
                                 f"= {m_by / max(1, n_l) / 1e6:.2f} MB",
@@ -267,7 +276,7 @@ def main():
                 rt.launch(14); rt.launch(15)
                 rt.collect(14, want_audio=False); rt.collect(15, want_audio=False)
             dt = time.perf_counter() - a
-            us_b, n_b, fl_b, _ = rt.time_subset(14, "conv_mfma", iters=10)
+            us_b, n_b, fl_b, _ = rt.time_subset(14, "conv_bf16" if bf16 else "conv_mfma", iters=10)
             out["batched_same_shape"] = {"batch": NBATCH, "slots_in_flight": 2, "utterances_per_sec": round(reps * 2 * NBATCH / dt, 1),
                                          "audio_sec_per_wall_sec": round(reps * 2 * NBATCH * audio_sec / dt, 1),
                                          "conv_kernel_tflops": round(fl_b / (us_b * n_b * 1e-6) / 1e12, 2) if us_b > 0 else None}

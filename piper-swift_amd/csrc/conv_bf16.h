@@ -12,6 +12,9 @@
 
 namespace ph {
 
+// the weight ring of conv_bf16_kernel prefetches up to 16 steps (16 × 64 lanes × 8 elements) past the last fragment of a
+// row tile: every packed image carries that many readable elements behind it (zero-filled by the pack kernels)
+constexpr int kBf16WeightPad = 16 * 64 * 8 * 2;
 constexpr int kC8Halo = 64;  // ≥ every "same" padding of a Piper generator (max (7·12−12)/2 = 36 medium, (11·5−5)/2 = 25 high)
 
 inline int64_t c8_round_len(int64_t L) { return (L + 127) / 128 * 128; }
@@ -37,7 +40,7 @@ struct ConvBf16Args {
   int ct_stride = 0, ct_pad = 0;
 };
 
-// bf16 elements of the packed fragment images
+// bf16 elements of the packed fragment images (including kBf16WeightPad)
 size_t packed_conv_bf16_elems(int Cout, int Cin, int K);
 size_t packed_convt_bf16_elems(int Cin, int Cout, int K, int stride);
 // w fp32 [Cout][Cin][K] → fragment image (round to nearest even)

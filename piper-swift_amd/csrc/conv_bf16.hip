@@ -10,7 +10,7 @@
 //      image (conv_bf16.h) into LDS with 16-byte loads; the stored zero halo of the image is the conv's zero padding,
 //      so the hot loop has no bounds tests and all K taps and all row tiles reuse the staged window;
 //   2. each wave owns MTW row tiles × NTW column tiles of 32×32 accumulators; per (tap, 16 channels) it takes the weight
-//      fragment (16 B per lane, contiguous per wave) from L2 through a 4-deep register ring and the activation fragment
+//      fragment (16 B per lane, contiguous per wave) from L2 through an 8-deep register ring and the activation fragment
 //      (ds_read_b128, conflict-free: 32 consecutive positions of one channel block) from the window, double-buffered;
 //   3. epilogue: bias, fp32 residual, MRF mean, fp32 store and/or the C8 bf16 image of LeakyReLU(result) for the next conv.
 #include "conv_bf16.h"
@@ -23,7 +23,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBT = 256;  // 4 waves
-constexpr int kDA = 4;    // weight-fragment ring depth (steps in flight)
 
 __device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
   bf16x2 v = {(__bf16)a, (__bf16)b};  // v_cvt_pk_bf16_f32, round to nearest even
@@ -87,7 +86,7 @@ __global__ __launch_bounds__(kBT) void pack_act_c8_kernel(const float* __restric
 // WM waves along rows × (4/WM) along columns; each wave MTW × NTW tiles of 32×32.
 template <int MTW, int NTW, int WM>
 __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
-  extern __shared__ __attribute__((aligned(16))) uint4 win[];  // [Cin/8][W] positions of 8 channels
+  extern __shared__ __attribute__((aligned(16))) uint4 win[];  // [Cin/8][W] positions of 8 channels + 1 dump slot
   constexpr int WN = 4 / WM;
   constexpr int NBC = WN * NTW * 32;  // columns per block
   const int lane = threadIdx.x & 63;
@@ -104,16 +103,49 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
   const int off_min = ct ? -(taps - 1) : -p.padL;
   const int off_max = ct ? (p.ct_stride - 1 + p.ct_pad) / p.ct_stride : (p.K - 1) * p.dil - p.padL;
   const int W = NBC + off_max - off_min;
+  const int S = taps * C16;  // steps: (tap, 16 channels)
+  // weight fragments: one 1 KB wave-load per step and row tile, streamed through a kDA-deep register ring. The image is
+  // padded by kBf16WeightPad elements (launcher contract), so the ring may run past the last step without a clamp.
+  constexpr int kDA = MTW == 1 ? 16 : 8;
+  // uniform base (SGPR pair) + 32-bit lane offset: the loads take the saddr form, no 64-bit VALU adds per step
+  const char* wa = (const char*)p.w + (int64_t)mt0 * S * 1024;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int64_t wtile = (int64_t)S * 1024;  // bytes per row tile
+  uint4 a[kDA][MTW];
+  auto load_a = [&](int slot, int ahead) {
+#pragma unroll
+    for (int m = 0; m < MTW; m++) a[slot][m] = *(const uint4*)(wa + m * wtile + ahead * 1024 + lane16);
+  };
+#pragma unroll
+  for (int d = 0; d < kDA - 1; d++) load_a(d, d);  // independent of the window: in flight before the staging round trips
   {
     const uint4* xb = (const uint4*)p.x + (int64_t)n * CB * p.x_row;
     const int g0 = kC8Halo + nb0 + off_min;
-    // rows of the window by wave, positions by lane: no per-element division, 1 KB contiguous per wave instruction
-    for (int cb = wave; cb < CB; cb += 4) {
-      const uint4* xr = xb + (int64_t)cb * p.x_row;
-      for (int wpos = lane; wpos < W; wpos += 64) {
+    // rows of the window by wave, 64 positions per wave instruction; kStage loads in flight before the first LDS store
+    // (one round trip per batch instead of one per row chunk). (row, chunk) are wave-uniform counters: no division.
+    // Every lane stores: lanes past the row end / rows past the window go to a dump slot behind it, so the loads are not
+    // sunk into conditional blocks (which would serialise them behind s_waitcnt vmcnt(0)).
+    constexpr int kStage = 8;
+    const int WCH = (W + 63) >> 6;
+    const int dump = CB * W;
+    int row = wave, chunk = 0;
+    while (row < CB) {
+      uint4 t[kStage];
+      int dst[kStage];
+#pragma unroll
+      for (int q = 0; q < kStage; q++) {
+        const int rr = min(row, CB - 1);
+        const int wpos = chunk * 64 + lane;
         const int gp = min(max(g0 + wpos, 0), p.x_row - 1);  // partial last block: clamped columns are masked at the store
-        win[cb * W + wpos] = xr[gp];
+        t[q] = xb[(int64_t)rr * p.x_row + gp];
+        dst[q] = (row < CB && wpos < W) ? rr * W + wpos : dump;
+        chunk++;
+        const bool wrap = chunk == WCH;
+        chunk = wrap ? 0 : chunk;
+        row += wrap ? 4 : 0;
       }
+#pragma unroll
+      for (int q = 0; q < kStage; q++) win[dst[q]] = t[q];
     }
   }
   __syncthreads();
@@ -126,52 +158,60 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
 #pragma unroll
       for (int q = 0; q < 16; q++) acc[m][j][q] = 0.0f;
 
-  const int S = taps * C16;  // steps: (tap, 16 channels)
-  const uint4* wp = (const uint4*)p.w + (int64_t)mt0 * S * 64 + lane;
-  const int64_t wtile = (int64_t)S * 64;
   // ConvTranspose: the wave's row tiles lie in one phase ρ when Cout % (32·MTW) == 0 (checked by the launcher)
   const int rho = ct ? (mt0 * 32) / p.Cout : 0;
-  const int ct_base = ct ? (rho + p.ct_pad) / p.ct_stride : 0;
+  // window position read by tap t: conv t·dil − padL, convT ⌊(ρ+pad)/s⌋ − t  ⇒  off0 + t·dstep
+  const int off0 = ct ? (rho + p.ct_pad) / p.ct_stride : -p.padL;
+  const int dstep = ct ? -1 : p.dil;
   // LDS read base of this lane: channel block h, position r + wave's column offset, relative to the window start
-  const int lbase = h * W + wn * NTW * 32 + r - off_min;
+  const int lbase = h * W + wn * NTW * 32 + r - off_min + off0;
 
-  uint4 a[kDA][MTW];
-  uint4 b[2][NTW];
-  auto fetch_a = [&](int slot, int step) {
-#pragma unroll
-    for (int m = 0; m < MTW; m++) a[slot][m] = wp[(int64_t)m * wtile + (int64_t)step * 64];
-  };
-  int tap_n = 0, c_n = 0;  // (tap, c16) of the next B fragment to read
+  // activation fragments: ds_read_b128 from the window, kDB steps ahead of their MFMA (LDS latency ≈ 3 MFMAs). The
+  // window index is a wave-uniform part (2·c16·W + tap·dstep, advanced with scalar selects: no branches, no multiplies)
+  // plus the lane part; it stops advancing after the last step, so the ring never reads outside the window.
+  constexpr int kDB = 4;
+  uint4 b[kDB][NTW];
+  int sidx = 0, c_n = 0, left = S - 1;
+  const int wrap_delta = dstep - 2 * W * (C16 - 1);
   auto read_b = [&](int slot) {
-    const int off = ct ? ct_base - tap_n : tap_n * p.dil - p.padL;
-    const int idx = lbase + 2 * c_n * W + off;
+    const int idx = lbase + sidx;
 #pragma unroll
     for (int j = 0; j < NTW; j++) b[slot][j] = win[idx + 32 * j];
-    if (++c_n == C16) {
-      c_n = 0;
-      if (tap_n + 1 < taps) ++tap_n; else c_n = C16 - 1;  // past the end: re-read the last fragment
-    }
+    c_n++;
+    const bool wrap = c_n == C16;
+    c_n = wrap ? 0 : c_n;
+    const int delta = wrap ? wrap_delta : 2 * W;
+    sidx += left > 0 ? delta : 0;
+    left--;
+  };
+  auto step = [&](int u) {  // u = static ring slot
+    load_a((u + kDA - 1) % kDA, kDA - 1 + u);
+    read_b((u + kDB - 1) % kDB);
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+      for (int j = 0; j < NTW; j++)
+        acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[u][m]),
+                                                            __builtin_bit_cast(bf16x8, b[u % kDB][j]), acc[m][j], 0, 0, 0);
   };
 #pragma unroll
-  for (int d = 0; d < kDA - 1; d++) fetch_a(d, min(d, S - 1));
-  read_b(0);
-  for (int s = 0; s < S; s += kDA) {
+  for (int d = 0; d < kDB - 1; d++) read_b(d);
+  const int full = S / kDA;
+  for (int g = 0; g < full; g++) {  // guard-free groups of kDA steps
 #pragma unroll
-    for (int u = 0; u < kDA; u++) {
-      fetch_a((u + kDA - 1) % kDA, min(s + u + kDA - 1, S - 1));  // unconditional (clamped): keeps vmcnt bookkeeping static
-      read_b((u + 1) & 1);
-      if (s + u < S) {
+    for (int u = 0; u < kDA; u++) step(u);
+    wa += kDA * 1024;
+  }
+  {
+    const int rem = S - full * kDA;  // wave-uniform tail
 #pragma unroll
-        for (int m = 0; m < MTW; m++)
-#pragma unroll
-          for (int j = 0; j < NTW; j++)
-            acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[u][m]),
-                                                                __builtin_bit_cast(bf16x8, b[u & 1][j]), acc[m][j], 0, 0, 0);
-      }
-    }
+    for (int u = 0; u < kDA - 1; u++)
+      if (u < rem) step(u);
   }
 
-  // ---- epilogue. accumulator register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r
+  // ---- epilogue. accumulator register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r.
+  // All loads of a tile (bias, residual, MRF partners) are issued up front with clamped, always-valid indices — no
+  // per-element branches, so they are one round trip instead of sixteen; only the stores are masked.
   const int rows_total = ct ? p.Cout * p.ct_stride : p.Cout;
   const int ACB = p.Cout >> 3;
 #pragma unroll
@@ -179,34 +219,56 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
     const int row0 = (mt0 + m) * 32;
     if (row0 >= rows_total) continue;
     const int co0 = ct ? row0 - rho * p.Cout : row0;  // channel of tile row 0
+    float bias_v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int coc = min(co0 + (q & 3) + 8 * (q >> 2) + 4 * h, p.Cout - 1);
+      bias_v[q] = p.bias ? p.bias[coc] : 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < NTW; j++) {
       const int col = nb0 + (wn * NTW + j) * 32 + r;
       const bool okc = col < p.Lout;
-      const int pos = ct ? col * p.ct_stride + rho : col;
+      const int colc = min(col, p.Lout - 1);
+      const int pos = ct ? colc * p.ct_stride + rho : colc;
+      int64_t yi[16];
+      float v[16];
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int cg = co0 + 8 * g + 4 * h;  // first of 4 consecutive channels
-        float v[4];
+      for (int q = 0; q < 16; q++) {
+        const int coc = min(co0 + (q & 3) + 8 * (q >> 2) + 4 * h, p.Cout - 1);
+        yi[q] = ((int64_t)n * p.Cout + coc) * p.y_len + pos;
+        v[q] = acc[m][j][q] + bias_v[q];
+      }
+      if (p.res) {
+        float t[16];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int co = cg + i;
-          const bool ok = okc && co < p.Cout;
-          float t = acc[m][j][4 * g + i] + (p.bias && co < p.Cout ? p.bias[co] : 0.0f);
-          const int64_t yi = ((int64_t)n * p.Cout + co) * p.y_len + pos;
-          if (ok) {
-            if (p.res) t += p.res[yi];
-            if (p.mrf_a) t = ((p.mrf_a[yi] + p.mrf_b[yi]) + t) / 3.0f;
-            if (p.y) p.y[yi] = t;
-          }
-          v[i] = t;
-        }
-        if (p.act && okc && cg < p.Cout) {
+        for (int q = 0; q < 16; q++) t[q] = p.res[yi[q]];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] += t[q];
+      }
+      if (p.mrf_a) {
+        float ta[16], tb[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { ta[q] = p.mrf_a[yi[q]]; tb[q] = p.mrf_b[yi[q]]; }
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = ((ta[q] + tb[q]) + v[q]) / 3.0f;
+      }
+      if (p.y) {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          if (okc && co0 + (q & 3) + 8 * (q >> 2) + 4 * h < p.Cout) p.y[yi[q]] = v[q];
+      }
+      if (p.act) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const int cg = co0 + 8 * g + 4 * h;  // first of 4 consecutive channels
           uint2 o;
-          o.x = pack2_bf16(lrelu1(v[0], p.act_alpha), lrelu1(v[1], p.act_alpha));
-          o.y = pack2_bf16(lrelu1(v[2], p.act_alpha), lrelu1(v[3], p.act_alpha));
-          uint2* ap = (uint2*)((uint4*)p.act + ((int64_t)n * ACB + (cg >> 3)) * p.act_row + kC8Halo + pos) + ((cg >> 2) & 1);
-          *ap = o;
+          o.x = pack2_bf16(lrelu1(v[4 * g], p.act_alpha), lrelu1(v[4 * g + 1], p.act_alpha));
+          o.y = pack2_bf16(lrelu1(v[4 * g + 2], p.act_alpha), lrelu1(v[4 * g + 3], p.act_alpha));
+          if (okc && cg < p.Cout) {
+            uint2* ap = (uint2*)((uint4*)p.act + ((int64_t)n * ACB + (cg >> 3)) * p.act_row + kC8Halo + pos) + ((cg >> 2) & 1);
+            *ap = o;
+          }
         }
       }
     }
@@ -227,11 +289,29 @@ void raise_lds() {
   }
 }
 
+int launch_cfg(hipStream_t s, const ConvBf16Args& a, int MTW, int NTW, int WM, dim3 grid, size_t lds) {
+#define PH_BF16_CASE(M, NT_, W_)                                 \
+  if (MTW == M && NTW == NT_ && WM == W_) {                      \
+    if (lds > 64 * 1024) raise_lds<M, NT_, W_>();                \
+    launch_inst<M, NT_, W_>(s, a, grid, lds);                    \
+  } else
+  PH_BF16_CASE(1, 1, 1) PH_BF16_CASE(1, 2, 1) PH_BF16_CASE(1, 4, 1)
+  PH_BF16_CASE(1, 1, 2) PH_BF16_CASE(1, 2, 2) PH_BF16_CASE(1, 4, 2)
+  PH_BF16_CASE(2, 1, 2) PH_BF16_CASE(2, 2, 2) PH_BF16_CASE(2, 4, 2)
+  PH_BF16_CASE(1, 1, 4) PH_BF16_CASE(1, 2, 4) PH_BF16_CASE(1, 4, 4)
+  PH_BF16_CASE(2, 1, 4) PH_BF16_CASE(2, 2, 4) PH_BF16_CASE(2, 4, 4)
+  PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_bf16: no instance for MTW=%d NTW=%d WM=%d", MTW, NTW, WM);
+#undef PH_BF16_CASE
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_bf16 launch failed: %s", hipGetErrorString(e));
+  return PIPER_HIP_OK;
+}
+
 }  // namespace
 
-size_t packed_conv_bf16_elems(int Cout, int Cin, int K) { return (size_t)((Cout + 31) / 32) * K * (Cin / 16) * 64 * 8; }
+size_t packed_conv_bf16_elems(int Cout, int Cin, int K) { return (size_t)((Cout + 31) / 32) * K * (Cin / 16) * 64 * 8 + kBf16WeightPad; }
 size_t packed_convt_bf16_elems(int Cin, int Cout, int K, int stride) {
-  return (size_t)((Cout * stride + 31) / 32) * (K / stride) * (Cin / 16) * 64 * 8;
+  return (size_t)((Cout * stride + 31) / 32) * (K / stride) * (Cin / 16) * 64 * 8 + kBf16WeightPad;
 }
 
 int pack_conv_weights_bf16(hipStream_t s, const float* w, int Cout, int Cin, int K, uint16_t* packed) {
@@ -278,28 +358,26 @@ int launch_conv_bf16(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args& a) {
   int MTW = (per_phase % (2 * WM) == 0) ? 2 : 1;
   int NTW = 4;
   auto blocks = [&](int mtw, int ntw) { return ceil_div(MT, WM * mtw) * ceil_div(a.Lout, WN * ntw * 32) * a.N; };
-  auto lds_bytes = [&](int ntw) { return (size_t)(a.Cin / 8) * (WN * ntw * 32 + reach) * 16; };
+  auto lds_bytes = [&](int ntw) { return (size_t)(a.Cin / 8) * (WN * ntw * 32 + reach) * 16 + 16; };
   const int64_t want = 2 * (int64_t)ctx->num_cus;  // keep every CU busy before growing the per-wave tile
   while (NTW > 1 && (blocks(MTW, NTW) < want || lds_bytes(NTW) > 160 * 1024)) NTW >>= 1;
   if (MTW == 2 && blocks(MTW, NTW) < want) MTW = 1;
+  if (const char* force = getenv("PIPER_HIP_BF16_CFG")) {  // tuning hook: "MTW,NTW,WM" (ignored when it does not divide the problem)
+    int m = 0, nt = 0, wmf = 0;
+    if (sscanf(force, "%d,%d,%d", &m, &nt, &wmf) == 3 && (wmf == 1 || wmf == 2 || wmf == 4) && per_phase % (wmf * m) == 0 &&
+        (m == 1 || (m == 2 && wmf > 1)) && (nt == 1 || nt == 2 || nt == 4)) {
+      const int wn = 4 / wmf;
+      const size_t fl = (size_t)(a.Cin / 8) * (wn * nt * 32 + reach) * 16 + 16;
+      if (fl <= 160 * 1024) {
+        const dim3 g((unsigned)ceil_div(a.Lout, wn * nt * 32), (unsigned)ceil_div(MT, wmf * m), (unsigned)a.N);
+        return launch_cfg(s, a, m, nt, wmf, g, fl);
+      }
+    }
+  }
   const size_t lds = lds_bytes(NTW);
   if (lds > 160 * 1024) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_bf16: window of %zu bytes does not fit LDS (Cin=%d reach=%d)", lds, a.Cin, reach);
   const dim3 grid((unsigned)ceil_div(a.Lout, WN * NTW * 32), (unsigned)ceil_div(MT, WM * MTW), (unsigned)a.N);
-#define PH_BF16_CASE(M, NT_, W_)                                 \
-  if (MTW == M && NTW == NT_ && WM == W_) {                      \
-    if (lds > 64 * 1024) raise_lds<M, NT_, W_>();                \
-    launch_inst<M, NT_, W_>(s, a, grid, lds);                    \
-  } else
-  PH_BF16_CASE(1, 1, 1) PH_BF16_CASE(1, 2, 1) PH_BF16_CASE(1, 4, 1)
-  PH_BF16_CASE(1, 1, 2) PH_BF16_CASE(1, 2, 2) PH_BF16_CASE(1, 4, 2)
-  PH_BF16_CASE(2, 1, 2) PH_BF16_CASE(2, 2, 2) PH_BF16_CASE(2, 4, 2)
-  PH_BF16_CASE(1, 1, 4) PH_BF16_CASE(1, 2, 4) PH_BF16_CASE(1, 4, 4)
-  PH_BF16_CASE(2, 1, 4) PH_BF16_CASE(2, 2, 4) PH_BF16_CASE(2, 4, 4)
-  PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_bf16: no instance for MTW=%d NTW=%d WM=%d", MTW, NTW, WM);
-#undef PH_BF16_CASE
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_bf16 launch failed: %s", hipGetErrorString(e));
-  return PIPER_HIP_OK;
+  return launch_cfg(s, a, MTW, NTW, WM, grid, lds);
 }
 
 }  // namespace ph

@@ -156,6 +156,7 @@ struct Slot {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool timed = false;
+  bool parallel = false;  // capture FORK/JOIN lanes as parallel graph branches (set by the schedule builder)
   int cur_lane = 0;  // lane given to steps added by add_conv
   // host staging (pinned so the H2D copies are truly async)
   int64_t* h_ids = nullptr;
@@ -423,7 +424,7 @@ void add_conv_bf16(piper_hip_voice* v, Slot& s, const std::string& name, const p
   const double cols = (double)a.N * a.Lout, out_cols = a.ct_stride > 0 ? cols * a.ct_stride : cols;
   st.bytes = 2.0 * (w.Cin * cols + (double)w.Cout * w.Cin * w.K) + (a.act ? 2.0 : 0.0) * w.Cout * out_cols +
              ((a.y ? 4.0 : 0.0) + (a.res ? 4.0 : 0.0) + (a.mrf_a ? 8.0 : 0.0)) * w.Cout * out_cols;
-  st.lane = 0;
+  st.lane = s.cur_lane;
   st.tag = "conv_bf16";
   s.steps.push_back(std::move(st));
 }
@@ -437,6 +438,8 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
   const int I = c.inter;
   const size_t B = (size_t)NB;
   hipStream_t zs = s.stream;
+  static const bool no_par = getenv("PIPER_HIP_BF16_SERIAL_RB") != nullptr;
+  s.parallel = !no_par && c.resblock_type == 1;  // 18 convs per stage (high) gain 10 %; the 6 of ResBlock2 (medium) do not
   auto image = [&](int C, int L) -> uint16_t* {  // zeroed once per build: kernels write the interior only
     const size_t bytes = (size_t)c8_elems(NB, C, L) * 2;
     void* p = ar.raw(bytes);
@@ -491,10 +494,20 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
       a.ct_stride = S.stride; a.ct_pad = S.pad;
       add_conv_bf16(v, s, p + "lrelu_convT", v->up_b[u], a, NB * 2.0 * S.Cin * S.Cout * (double)S.K * L);
     }
+    // The stage's three ResBlocks are independent chains of short, latency-bound launches that leave most CUs idle:
+    // rb0 / rb1 run as side branches of the graph, rb2 on the main lane, joined before rb2's last conv (which folds the
+    // MRF mean over all three).
+    if (s.parallel) {
+      Step f;
+      f.name = p + "fork";
+      f.kind = Step::FORK;
+      s.steps.push_back(f);
+    }
     for (int j = 0; j < c.n_rb; j++) {
       const int K = c.rb_kernels[j];
       const float* src = up;
       const uint16_t* src_act = a_up;
+      s.cur_lane = (j + 1 == c.n_rb) ? 0 : j + 1;
       for (int di = 0; di < c.rb_n_dil; di++) {
         const int dil = c.rb_dilations[j][di];
         const bool lastd = di + 1 == c.rb_n_dil;
@@ -514,13 +527,22 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
           return a;
         };
         const double fl = NB * conv_flops(S.Cout, S.Cout, K, Lo);
+        auto join = [&]() {
+          if (!(fuse_mean && s.parallel)) return;
+          Step jn;
+          jn.name = p + "join";
+          jn.kind = Step::JOIN;
+          s.steps.push_back(jn);
+        };
         if (c.resblock_type == 1) {
           ConvBf16Args a1 = rbconv(src_act, dil);
           a1.act = mid[j];
           add_conv_bf16(v, s, nm + "a_lrelu_conv", v->rb_b[u][j][2 * di], a1, fl);
+          join();
           add_conv_bf16(v, s, nm + (fuse_mean ? "b_lrelu_conv_res_mrfmean" : "b_lrelu_conv_res"), v->rb_b[u][j][2 * di + 1],
                         finish(rbconv(mid[j], 1)), fl);
         } else {
+          join();
           add_conv_bf16(v, s, nm + (fuse_mean ? "_lrelu_conv_res_mrfmean" : "_lrelu_conv_res"), v->rb_b[u][j][di],
                         finish(rbconv(src_act, dil)), fl);
         }
@@ -528,6 +550,7 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
         src_act = dst_act;
       }
     }
+    s.cur_lane = 0;
     a_in = a_next;
     mean = m;
     L = Lo;
@@ -556,6 +579,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;
+  s.parallel = parallel_rb;
   const size_t B = (size_t)NB;
   s.ids = (int64_t*)ar.raw(B * T * sizeof(int64_t));
   s.frame2id = (int32_t*)ar.raw(B * F * sizeof(int32_t));
@@ -1107,10 +1131,10 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
       PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
     }
     PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
-    // Parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three short kernels
-    // gain: factor 1 1.34 → 1.50 ms, factor 8 1.65 → 1.89 ms), so the graph stays a single chain unless asked otherwise.
-    static const bool par = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
-    rc = run_schedule(s, s.stream, par);
+    // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
+    // short kernels gain: factor 1 1.34 → 1.50 ms, factor 8 1.65 → 1.89 ms), so that graph stays a single chain unless
+    // asked otherwise. The bf16 generator's builder decides for itself (s.parallel).
+    rc = run_schedule(s, s.stream, s.parallel);
     hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
     if (rc || ce != hipSuccess) {
       slot_release(v, s, false);
