@@ -111,6 +111,59 @@ __device__ __forceinline__ void store_elem(const ConvArgs& p, int n, int row, in
   }
 }
 
+// Two-phase epilogue of the MFMA kernels. A wave's tile has NR·NT elements; with the loads of store_mode sitting inside
+// per-element bounds tests, every element was its own load → wait → store round trip (≈ 0.5 µs each, 16-64 per wave).
+// epi_load fetches what the mode ADDS to the accumulator from clamped, always-valid indices (so all of a tile's loads
+// are in flight together, unconditionally); epi_finish does the arithmetic and the (masked) store. The arithmetic and
+// its order are exactly store_mode's.
+struct EpiIn {
+  float a, b, c;
+};
+template <int MODE>
+__device__ __forceinline__ EpiIn epi_load(const ConvArgs& p, int n, int row, int col) {
+  EpiIn e{0.0f, 0.0f, 0.0f};
+  if constexpr (MODE == EPI_STORE || MODE == EPI_RSUB) {
+    const int idx = (p.out_ch_base + p.out_ch_sign * row) * p.y_len + col;
+    if (MODE == EPI_RSUB || p.res) e.a = (p.res + (int64_t)n * p.y_batch_stride)[idx];
+  } else if constexpr (MODE == EPI_WN_RES_SKIP) {
+    if (row < p.wn_c) {
+      e.a = (p.res + (int64_t)n * p.y_batch_stride)[row * p.y_len + col];
+    } else if (p.skip) {
+      e.a = (p.skip + (int64_t)n * p.y2_batch_stride)[(row - p.wn_c) * p.y_len + col];
+    }
+  } else if constexpr (MODE == EPI_WN_SKIP_LAST) {
+    if (p.skip) e.a = (p.skip + (int64_t)n * p.y2_batch_stride)[row * p.y_len + col];
+  } else if constexpr (MODE == EPI_MRF_MEAN) {
+    const int idx = row * p.y_len + col;
+    const int64_t bo = (int64_t)n * p.y_batch_stride;
+    e.a = (p.res + bo)[idx];
+    e.b = (p.mrf_a + bo)[idx];
+    e.c = (p.mrf_b + bo)[idx];
+  }
+  return e;
+}
+template <int MODE>
+__device__ __forceinline__ void epi_finish(const ConvArgs& p, int n, int row, int col, float v, const EpiIn& e) {
+  if constexpr (MODE == EPI_STORE) {
+    const int idx = (p.out_ch_base + p.out_ch_sign * row) * p.y_len + col;
+    (p.y + (int64_t)n * p.y_batch_stride)[idx] = p.res ? v + e.a : v;
+  } else if constexpr (MODE == EPI_RSUB) {
+    const int idx = (p.out_ch_base + p.out_ch_sign * row) * p.y_len + col;
+    (p.y + (int64_t)n * p.y_batch_stride)[idx] = e.a - v;
+  } else if constexpr (MODE == EPI_WN_RES_SKIP) {
+    if (row < p.wn_c) (p.y + (int64_t)n * p.y_batch_stride)[row * p.y_len + col] = e.a + v;
+    else (p.y2 + (int64_t)n * p.y2_batch_stride)[(row - p.wn_c) * p.y_len + col] = e.a + v;
+  } else if constexpr (MODE == EPI_WN_SKIP_LAST) {
+    (p.y2 + (int64_t)n * p.y2_batch_stride)[row * p.y_len + col] = e.a + v;
+  } else if constexpr (MODE == EPI_MRF_MEAN) {
+    const float r2 = v + e.a;
+    const float m = ((e.b + e.c) + r2) / 3.0f;
+    (p.y + (int64_t)n * p.y_batch_stride)[row * p.y_len + col] = lrelu(m, p.alpha2);
+  } else {
+    store_mode<MODE>(p, n, row, col, v);  // RELU / TANH / CONVT add nothing from memory
+  }
+}
+
 template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) {
@@ -324,14 +377,16 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
       const int col = t0 + TM * nt + j;
-      if (col >= p.Lout) continue;
+      const int colc = min(col, p.Lout - 1);
+      EpiIn e[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) e[r] = epi_load<MODE>(p, n, min(mt * TM + acc_row_t<TM>(r, lane), rows_out - 1), colc);
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         const int row = mt * TM + acc_row_t<TM>(r, lane);
-        if (row >= rows_out) continue;
         float v = acc[0][nt][r];
         if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
-        store_mode<MODE>(p, n, row, col, v);
+        if (col < p.Lout && row < rows_out) epi_finish<MODE>(p, n, row, col, v, e[r]);
       }
     }
   };
@@ -496,15 +551,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
       const int col = t0 + wave * (32 * NTW) + 32 * nt + j;
-      if (col >= p.Lout) continue;
+      const int colc = min(col, p.Lout - 1);
 #pragma unroll
-      for (int m = 0; m < MT; m++)
+      for (int m = 0; m < MT; m++) {
+        EpiIn e[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) e[r] = epi_load<MODE>(p, n, min((mt0 + m) * 32 + acc_row(r, lane), p.Cout - 1), colc);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int row = (mt0 + m) * 32 + acc_row(r, lane);
-          if (row >= p.Cout) continue;
-          store_mode<MODE>(p, n, row, col, acc[m][nt][r]);
+          if (col < p.Lout && row < p.Cout) epi_finish<MODE>(p, n, row, col, acc[m][nt][r], e[r]);
         }
+      }
     }
   };
   switch (p.epilogue) {  // wave-uniform
