@@ -189,10 +189,13 @@ def main():
             peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
             achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0
             traffic = None
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r1_rocprof_summary.json")))
+            try:  # HBM bytes per launch of this kernel family from the committed PMC passes of the same command
                 if args.factor == 8 and args.quality == "medium" and not bf16:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", "r1b_rocprof_summary.json")))
                     traffic = pj["traffic"]["conv_stream_kernel"]["hbm_mb_per_launch"] * 1e6
+                elif args.factor == 8 and args.quality == "high" and bf16:
+                    pj = json.load(open(os.path.join(ROOT, "profiles", "r1b_high_bf16_rocprof_summary.json")))
+                    traffic = pj["traffic"]["conv_bf16_kernel"]["hbm_mb_per_launch"] * 1e6
             except Exception:
                 pass
             out["roofline"] = {
@@ -201,7 +204,7 @@ def main():
                            "conv_stream_kernel (fp32 MFMA implicit-GEMM Conv1d/ConvTranspose1d; all of its launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r1_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "traffic_note": "HBM bytes per launch from profiles/r1b*_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; algorithmic bytes per launch "
                                 f"= {m_by / max(1, n_l) / 1e6:.2f} MB",
                 "timing": "HIP events around a graph replay of only these launches (30 replays)",

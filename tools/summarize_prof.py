@@ -21,13 +21,13 @@ def find(d, suffix):
 
 
 def short(name):
-    name = name.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    name = name.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("ph::detail::", "")
     return name.split("(")[0]
 
 
 def family(name):
     n = short(name)
-    for f in ("conv_stream_kernel", "conv_tile_kernel", "conv_small_cout_kernel", "conv_direct_kernel", "rel_attention_kernel",
+    for f in ("conv_bf16_kernel", "pack_act_c8_kernel", "conv_stream_kernel", "conv_tile_kernel", "conv_small_cout_kernel", "conv_direct_kernel", "rel_attention_kernel",
               "add_layernorm_kernel", "mrf_mean_lrelu_kernel", "embed_kernel", "expand_noise_kernel", "pack_conv"):
         if n.startswith(f):
             return f
@@ -50,6 +50,7 @@ def main():
     out = {"round": tag}
     rows = list(csv.DictReader(open(find(stats_dir, "kernel_stats.csv"))))
     fam = collections.defaultdict(lambda: [0, 0.0])
+    rows = [r for r in rows if "spin_kernel" not in r["Name"]]  # timing scaffold of piper_hip_voice_profile, not the path
     for r in rows:
         k = family(r["Name"])
         fam[k][0] += int(r["Calls"])
