@@ -186,6 +186,7 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
   };
   auto step = [&](int u) {  // u = static ring slot
     load_a((u + kDA - 1) % kDA, kDA - 1 + u);
+    __builtin_amdgcn_sched_barrier(0);  // keep the ring's load at the top of its step (the scheduler otherwise clusters them)
     read_b((u + kDB - 1) % kDB);
 #pragma unroll
     for (int m = 0; m < MTW; m++)
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
   };
 #pragma unroll
   for (int d = 0; d < kDB - 1; d++) read_b(d);
+  // the ring's first loads were issued before the staging loop and have landed: an explicit vmcnt(0) gives the waitcnt pass
+  // a clean state at the loop header (otherwise the first wait of each iteration inherits the staging loop's pending loads)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   const int full = S / kDA;
   for (int g = 0; g < full; g++) {  // guard-free groups of kDA steps
 #pragma unroll

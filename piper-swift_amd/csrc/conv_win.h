@@ -1,0 +1,40 @@
+// conv_win.h — internal interface of the fp32 "window" Conv1d / ConvTranspose1d kernel (conv_win.hip).
+//
+// Same contraction as conv_stream_kernel (exact fp32 on v_mfma_f32_32x32x2_f32) for the long-row convs of the HiFi-GAN
+// generator, organised like conv_bf16_kernel: the block's input window is staged ONCE into LDS (LeakyReLU and the zero
+// padding applied on the way in), weight fragments stream from L2 through a register ring, and small problems split the
+// contraction over the block's waves (fixed-order reduction through LDS).
+#pragma once
+#include "common.h"
+
+namespace ph {
+
+struct ConvWinArgs {
+  const float* x = nullptr;     // fp32 [N][Cin][Lin]
+  const float* w4 = nullptr;    // fragment image (pack_conv_weights_win / pack_convt_weights_win)
+  const float* bias = nullptr;  // [Cout] or null
+  const float* res = nullptr;   // [N][Cout][y_len] added to the result, may be null
+  const float* mrf_a = nullptr; // both set: result = ((mrf_a + mrf_b) + result) / 3
+  const float* mrf_b = nullptr;
+  float* y = nullptr;           // [N][Cout][y_len]
+  float pro_alpha = 1.0f;       // LeakyReLU slope applied to x while staging (1 ⇒ none)
+  float out_alpha = 1.0f;       // LeakyReLU slope applied to the final value (1 ⇒ none)
+  int N = 1, Cin = 0, Cout = 0, K = 1, dil = 1, padL = 0;
+  int Lin = 0;                  // input row length (multiple of 4)
+  int Lout = 0;                 // GEMM columns (conv: output length; convT: input length)
+  int y_len = 0;                // row length of y / res / mrf_*
+  int ct_stride = 0, ct_pad = 0;  // ConvTranspose1d: rows (phase ρ, co), K/s taps, output position s·q + ρ
+};
+
+size_t packed_conv_win_floats(int Cout, int Cin, int K);
+size_t packed_convt_win_floats(int Cin, int Cout, int K, int stride);
+int pack_conv_weights_win(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
+int pack_convt_weights_win(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, int pad, float* packed);
+
+// geometry covered: stride 1, groups 1, Cin even, Lin % 4 == 0, window within LDS
+bool conv_win_eligible(int Cout, int Cin, int K, int dil, int padL, int Lin, int Lout);
+bool convt_win_eligible(int Cin, int Cout, int K, int stride, int pad, int Lin);
+
+int launch_conv_win(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs& a);
+
+}  // namespace ph

@@ -20,6 +20,7 @@
 #include "../../include/piper_hip_voice_layout.h"
 #include "conv.h"
 #include "conv_bf16.h"
+#include "conv_win.h"
 
 namespace ph {
 int validate_config(const piper_hip_voice_config* c);
@@ -130,6 +131,7 @@ struct Step {
 struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bias pointer into the resident blob
   const float* w = nullptr;
   const float* w16 = nullptr;  // 16-wide fragment image (short-utterance geometry)
+  const float* w4 = nullptr;   // conv_win_kernel fragment image (generator convs: long rows)
   const float* bias = nullptr;
   int Cout = 0, Cin = 0, K = 1;
   bool mfma = false;
@@ -233,7 +235,7 @@ struct Packer {  // bump allocator over the packed-weights allocation
 };
 
 // Registers one conv. dry = true only measures the packed size.
-ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true) {
+ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true, bool win = false) {
   ConvW c;
   c.Cout = Cout; c.Cin = Cin; c.K = K;
   c.mfma = conv_mfma_eligible(Cout, Cin, K, 1, 1);
@@ -246,6 +248,11 @@ ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int C
     float* p16 = pk.take(packed_conv_floats(Cout, Cin, K, 16));
     if (!dry) pack_conv_weights(pk.s, w, Cout, Cin, K, p16, 16);
     c.w16 = p16;
+    if (win) {
+      float* p4 = pk.take(packed_conv_win_floats(Cout, Cin, K));
+      if (!dry) pack_conv_weights_win(pk.s, w, Cout, Cin, K, p4);
+      c.w4 = p4;
+    }
   } else {
     c.w = w;
   }
@@ -319,8 +326,12 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
     float* p16 = pk.take(packed_convt_floats(S.Cin, S.Cout, S.K, S.stride, 16));
     S.up.w = p;
     S.up.w16 = p16;
+    const bool ct_win = convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, 4);
+    float* p4 = ct_win ? pk.take(packed_convt_win_floats(S.Cin, S.Cout, S.K, S.stride)) : nullptr;
+    S.up.w4 = ct_win ? p4 : nullptr;
     if (!dry) {
       snprintf(nm, sizeof nm, "dec.ups.%d", u);
+      if (ct_win) pack_convt_weights_win(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, S.pad, p4);
       pack_convt_weights(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, p);
       pack_convt_weights(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, p16, 16);
       S.up.bias = tensor(v, std::string(nm) + ".bias");
@@ -332,12 +343,12 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
       for (int d = 0; d < c.rb_n_dil; d++) {
         if (c.resblock_type == 1) {
           snprintf(nm, sizeof nm, "dec.resblocks.%d.convs1.%d", rb, d);
-          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j], true, true));
           snprintf(nm, sizeof nm, "dec.resblocks.%d.convs2.%d", rb, d);
-          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j], true, true));
         } else {
           snprintf(nm, sizeof nm, "dec.resblocks.%d.convs.%d", rb, d);
-          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j]));
+          convs.push_back(make_conv(pk, dry, nm, ch, ch, c.rb_kernels[j], true, true));
         }
       }
       S.rb.push_back(convs);
@@ -576,6 +587,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
   slot_release(v, s, false);
   static const bool parallel_rb = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
+  static const bool use_win = getenv("PIPER_HIP_NO_WIN") == nullptr;  // window kernel for the generator's long rows
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;
@@ -774,6 +786,14 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
       Step st;
       st.name = p + "lrelu_convT";
       st.tag = "conv_mfma";
+      if (use_win && S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L)) {
+        ConvWinArgs wa;
+        wa.x = cur[0]; wa.w4 = S.up.w4; wa.bias = S.up.bias; wa.y = up;
+        wa.pro_alpha = cur_is_mrf ? 1.0f : 0.1f;
+        wa.N = NB; wa.Cin = S.Cin; wa.Cout = S.Cout; wa.K = S.K; wa.Lin = L; wa.Lout = L; wa.y_len = Lo;
+        wa.ct_stride = S.stride; wa.ct_pad = S.pad;
+        st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
+      } else
       st.run = [ctx, a](hipStream_t q) { return launch_conv_mfma(ctx, q, a); };
       st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
       st.bytes = NB * 4.0 * ((double)S.Cin * L + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
@@ -811,13 +831,34 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
           }
           return a;
         };
+        // long rows: the window kernel (conv_win.hip); otherwise the streaming kernel
+        auto add_rb = [&](const std::string& name, const ConvW& w, const ConvArgs& a) {
+          if (!(use_win && w.w4 && conv_win_eligible(w.Cout, w.Cin, w.K, a.dil, a.padL, Lo, Lo))) {
+            add_conv(v, s, name, w, a, Lo);
+            return;
+          }
+          ConvWinArgs wa;
+          wa.x = a.x; wa.w4 = w.w4; wa.bias = w.bias; wa.res = a.res; wa.y = a.y;
+          wa.pro_alpha = a.alpha;
+          if (a.epilogue == EPI_MRF_MEAN) { wa.mrf_a = a.mrf_a; wa.mrf_b = a.mrf_b; wa.out_alpha = a.alpha2; }
+          wa.N = NB; wa.Cin = w.Cin; wa.Cout = w.Cout; wa.K = w.K; wa.dil = a.dil; wa.padL = a.padL;
+          wa.Lin = Lo; wa.Lout = Lo; wa.y_len = Lo;
+          Step st;
+          st.name = name;
+          st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
+          st.flops = NB * conv_flops(w.Cout, w.Cin, w.K, Lo);
+          st.bytes = NB * conv_bytes(w.Cin, w.Cout, w.K, Lo);
+          st.lane = s.cur_lane;
+          st.tag = "conv_mfma";
+          s.steps.push_back(std::move(st));
+        };
         if (c.resblock_type == 1) {
-          add_conv(v, s, nm + "a_lrelu_conv", S.rb[j][2 * di], rbconv(src, nullptr, mid[j], dil), Lo);
-          add_conv(v, s, nm + (fuse_mean ? "b_lrelu_conv_res_mrfmean" : "b_lrelu_conv_res"), S.rb[j][2 * di + 1],
-                   with_mean(rbconv(mid[j], src, dst, 1)), Lo);
+          add_rb(nm + "a_lrelu_conv", S.rb[j][2 * di], rbconv(src, nullptr, mid[j], dil));
+          add_rb(nm + (fuse_mean ? "b_lrelu_conv_res_mrfmean" : "b_lrelu_conv_res"), S.rb[j][2 * di + 1],
+                 with_mean(rbconv(mid[j], src, dst, 1)));
         } else {
-          add_conv(v, s, nm + (fuse_mean ? "_lrelu_conv_res_mrfmean" : "_lrelu_conv_res"), S.rb[j][di],
-                   with_mean(rbconv(src, src, dst, dil)), Lo);
+          add_rb(nm + (fuse_mean ? "_lrelu_conv_res_mrfmean" : "_lrelu_conv_res"), S.rb[j][di],
+                 with_mean(rbconv(src, src, dst, dil)));
         }
         src = dst;
       }

@@ -204,3 +204,21 @@ CONVT_BF16_CASES = [
     (128, 64, 4, 2, 129, 1),
     (512, 256, 16, 8, 20, 1),
 ]
+
+# long-row fp32 cases routed to the window kernel (conv_win.hip): (Cin, Cout, K, dil, padL, padR, L, N, bias)
+CONV_WIN_CASES = [
+    (32, 32, 7, 1, 3, 3, 4096, 1, True),       # C=32: 4 waves side by side along the columns
+    (64, 64, 3, 5, 5, 5, 2048, 2, True),       # 2×2 waves, batch 2
+    (128, 128, 7, 12, 36, 36, 2688, 1, True),  # medium stage 0 at factor 8: K-split over the block's waves
+    (128, 128, 3, 1, 1, 1, 1024, 1, False),    # K-split 4, no bias
+    (32, 40, 5, 2, 3, 5, 1300, 1, True),       # ragged Cout, asymmetric pads, L % 4 == 0 but not % 32
+    (256, 256, 11, 5, 25, 25, 1344, 1, True),  # high stage 0, widest window (Cin × reach)
+    (34, 48, 3, 3, 3, 3, 1028, 1, True),       # odd channel-pair count (17): step padding inside a K range
+]
+# (Cin, Cout, K, stride, L, N)
+CONVT_WIN_CASES = [
+    (128, 64, 16, 8, 2688, 1),
+    (64, 32, 8, 4, 1024, 2),
+    (256, 128, 16, 8, 336, 1),
+    (128, 64, 4, 2, 260, 1),
+]

@@ -380,3 +380,31 @@ def test_bf16_variants_refuse_uncovered_geometry(backend):
         backend.convTranspose1dBF16(x, [1, 32, 16], w, [32, 32, 3], None, stride=2)  # K % stride != 0
     with pytest.raises(ph.ShapeMismatch):
         backend.conv1dBF16(x, [1, 32, 16], w, [32, 16, 3], None)
+
+
+# ---- long rows: conv1dF32 / convTranspose1dF32 route to the fp32 window kernel (conv_win.hip)
+@pytest.mark.parametrize("idx", range(len(kd.CONV_WIN_CASES)))
+def test_conv1d_long_rows_window_kernel(idx, backend):
+    Cin, Cout, K, d, pl, pr, L, N, has_b = kd.CONV_WIN_CASES[idx]
+    x = kd.sym(SD + 1200 + idx, (N, Cin, L))
+    w = kd.weight(SD + 1250 + idx, (Cout, Cin, K), Cin * K)
+    b = kd.sym(SD + 1290 + idx, (Cout,), 0.1) if has_b else None
+    out, shp = backend.conv1dF32(up(backend, x), list(x.shape), up(backend, w), list(w.shape),
+                                 None if b is None else up(backend, b), dilation=d, padL=pl, padR=pr)
+    ref = orc.conv1d(x, w, b, 1, d, pl, pr)
+    assert shp == list(ref.shape)
+    assert_close(dl(backend, out, shp), ref, OP_TOL, f"conv1d window case {idx}")
+
+
+@pytest.mark.parametrize("idx", range(len(kd.CONVT_WIN_CASES)))
+def test_convtranspose1d_long_rows_window_kernel(idx, backend):
+    Cin, Cout, K, s, L, N = kd.CONVT_WIN_CASES[idx]
+    pad = (K - s) // 2
+    x = kd.sym(SD + 1300 + idx, (N, Cin, L))
+    w = kd.weight(SD + 1350 + idx, (Cin, Cout, K), Cin * K // s)
+    b = kd.sym(SD + 1390 + idx, (Cout,), 0.1)
+    out, shp = backend.convTranspose1dF32(up(backend, x), list(x.shape), up(backend, w), list(w.shape), up(backend, b),
+                                          stride=s, padL=pad, padR=pad)
+    ref = orc.convtranspose1d(x, w, b, s, 1, pad, pad)
+    assert shp == list(ref.shape)
+    assert_close(dl(backend, out, shp), ref, OP_TOL, f"convT window case {idx}")
