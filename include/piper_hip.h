@@ -291,6 +291,39 @@ void piper_hip_voice_destroy(piper_hip_voice* v);
 int piper_hip_voice_set_precision(piper_hip_voice* v, int precision);
 int piper_hip_voice_precision(const piper_hip_voice* v);
 
+/* ---- Piper `.onnx` / `.onnx.json` → voice blob (role of Sources/PiperONNX for this library) ----
+ * Host-only (no GPU). Decodes the protobuf wire subset the reference's loader decodes (ONNXLoader.swift:34-37, 94-99,
+ * 170-176, 214-223, 321-327): initializers (name, dims, data_type, float_data / raw_data little-endian, the flat order of
+ * TensorValue.swift:45-116) and the Conv / ConvTranspose node attributes (strides, dilations). `infer_config` derives the
+ * voice geometry from initializer shapes + those attributes; `build_blob` emits the initializers in the order of
+ * include/piper_hip_voice_layout.h (names = the ONNX initializer names, e.g. `enc_p.encoder.attn_layers.0.conv_q.weight`,
+ * ONNXParsingTests.swift:32), folding `weight_g`/`weight_v` pairs if the export kept weight norm. Tested against ONNX files
+ * WRITTEN by the test-suite (no Piper voice exists offline): real-voice naming is unpinned. */
+typedef struct piper_hip_onnx piper_hip_onnx;
+typedef struct {
+  char name[128];
+  int32_t data_type; /* ONNX TensorProto.DataType: 1 FLOAT, 6 INT32, 7 INT64, 9 BOOL */
+  int32_t rank;
+  int64_t dims[8];
+  int64_t count;
+} piper_hip_onnx_tensor_info;
+int piper_hip_onnx_open(const char* path, piper_hip_onnx** out); /* mmap: weights are copied once, by build_blob */
+int piper_hip_onnx_open_memory(const void* data, size_t size, piper_hip_onnx** out);
+void piper_hip_onnx_close(piper_hip_onnx* m);
+/* ir_version, default-domain opset, node and initializer counts (ONNXParsingTests.swift:22-36 pins 15 / 2755 / 401). */
+int piper_hip_onnx_counts(const piper_hip_onnx* m, int64_t* ir_version, int64_t* opset, int* n_nodes, int* n_initializers);
+int piper_hip_onnx_initializer(const piper_hip_onnx* m, int index, piper_hip_onnx_tensor_info* out);
+int piper_hip_onnx_find(const piper_hip_onnx* m, const char* name); /* initializer index or -1 */
+int piper_hip_onnx_read_f32(const piper_hip_onnx* m, int index, float* dst, size_t n);
+int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voice_config* cfg);
+int piper_hip_onnx_build_blob(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats);
+/* The numbers this library needs from the voice's `.onnx.json` (PiperConfig.swift:3-47). */
+typedef struct {
+  int32_t sample_rate, num_symbols, num_speakers;
+  float noise_scale, length_scale, noise_w;
+} piper_hip_piper_json_info;
+int piper_hip_piper_json(const char* json_text, piper_hip_piper_json_info* out);
+
 /* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104). The duration
  * predictor is outside this library's scope, so per-id frame counts are supplied (the reference's own
  * `overrides` mechanism); `noise` is the "main" RandomNormalLike tensor [inter, F] injected by name

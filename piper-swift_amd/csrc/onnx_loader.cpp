@@ -1,0 +1,485 @@
+// onnx_loader.cpp — reads a Piper VITS `.onnx` (protobuf wire subset) and turns it into the packed voice blob.
+//
+// Role of Sources/PiperONNX (ONNXLoader.swift:25-387, ONNXIR.swift) for THIS library: SURVEY.md §8f row 1. Only what the
+// hot path needs is decoded — ModelProto{1 ir_version, 7 graph, 8 opset_import}, GraphProto{1 node, 5 initializer},
+// NodeProto{1 input, 4 op_type, 5 attribute}, AttributeProto{1 name, 3 i, 8 ints}, TensorProto{1 dims, 2 data_type,
+// 4 float_data, 8 name, 9 raw_data} (the same field numbers the reference lists at ONNXLoader.swift:34-37, 94-99, 170-176,
+// 214-223, 321-327); every other field is skipped by wire type. Host-only: no GPU is touched here.
+//
+// From the initializer shapes and the Conv / ConvTranspose attributes it infers the voice geometry
+// (piper_hip_voice_config) and emits the initializers in the order include/piper_hip_voice_layout.h fixes, folding
+// weight-norm pairs (weight_g, weight_v) if an export left them in.
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+
+#include "../../include/piper_hip_voice_layout.h"
+#include "common.h"
+
+using namespace ph;
+
+namespace {
+
+struct Reader {  // protobuf wire format
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  bool at_end() const { return p >= end || !ok; }
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int shift = 0; shift < 64 && p < end; shift += 7) {
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+    }
+    ok = false;
+    return 0;
+  }
+  Reader sub() {  // length-delimited payload
+    const uint64_t n = varint();
+    if (!ok || n > (uint64_t)(end - p)) { ok = false; return Reader{p, p}; }
+    Reader r{p, p + n};
+    p += n;
+    return r;
+  }
+  void skip(int wire) {
+    switch (wire) {
+      case 0: (void)varint(); break;
+      case 1: if (end - p >= 8) p += 8; else ok = false; break;
+      case 2: (void)sub(); break;
+      case 5: if (end - p >= 4) p += 4; else ok = false; break;
+      default: ok = false;
+    }
+  }
+};
+
+struct Tensor {
+  std::string name;
+  int dtype = 0;  // ONNX TensorProto.DataType: 1 = FLOAT, 7 = INT64
+  std::vector<int64_t> dims;
+  const uint8_t* raw = nullptr;  size_t raw_len = 0;    // field 9
+  const uint8_t* fdat = nullptr; size_t fdat_len = 0;   // field 4, packed
+  std::vector<float> floats_unpacked;                    // field 4, unpacked encoding (rare)
+  int64_t count() const {
+    int64_t n = 1;
+    for (int64_t d : dims) n *= d;
+    return n;
+  }
+};
+
+struct ConvNode {  // Conv / ConvTranspose with an initializer as weight
+  std::string op, weight;
+  int64_t stride = 1, dilation = 1, group = 1, pad_l = 0, pad_r = 0;
+};
+
+}  // namespace
+
+struct piper_hip_onnx {
+  std::vector<uint8_t> owned;          // open_memory copy
+  const uint8_t* data = nullptr;
+  size_t size = 0;
+  void* map = nullptr;
+  size_t map_len = 0;
+  int64_t ir_version = 0, opset = 0;
+  int n_nodes = 0;
+  std::vector<Tensor> tensors;
+  std::map<std::string, int> by_name;
+  std::map<std::string, ConvNode> conv_by_weight;
+};
+
+namespace {
+
+bool parse_tensor(Reader r, Tensor& t) {
+  while (!r.at_end()) {
+    const uint64_t tag = r.varint();
+    const int field = (int)(tag >> 3), wire = (int)(tag & 7);
+    if (field == 1 && wire == 2) {  // dims, packed
+      Reader d = r.sub();
+      while (!d.at_end()) t.dims.push_back((int64_t)d.varint());
+    } else if (field == 1 && wire == 0) {
+      t.dims.push_back((int64_t)r.varint());
+    } else if (field == 2 && wire == 0) {
+      t.dtype = (int)r.varint();
+    } else if (field == 4 && wire == 2) {
+      Reader d = r.sub();
+      t.fdat = d.p; t.fdat_len = (size_t)(d.end - d.p);
+    } else if (field == 4 && wire == 5) {
+      if (r.end - r.p < 4) return false;
+      float f; memcpy(&f, r.p, 4); r.p += 4;
+      t.floats_unpacked.push_back(f);
+    } else if (field == 8 && wire == 2) {
+      Reader d = r.sub();
+      t.name.assign((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 9 && wire == 2) {
+      Reader d = r.sub();
+      t.raw = d.p; t.raw_len = (size_t)(d.end - d.p);
+    } else {
+      r.skip(wire);
+    }
+  }
+  return r.ok;
+}
+
+bool parse_node(Reader r, piper_hip_onnx* m) {
+  std::vector<std::string> inputs;
+  std::string op;
+  ConvNode c;
+  bool has_pads = false;
+  while (!r.at_end()) {
+    const uint64_t tag = r.varint();
+    const int field = (int)(tag >> 3), wire = (int)(tag & 7);
+    if (field == 1 && wire == 2) {
+      Reader d = r.sub();
+      inputs.emplace_back((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 4 && wire == 2) {
+      Reader d = r.sub();
+      op.assign((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 5 && wire == 2) {  // AttributeProto
+      Reader a = r.sub();
+      std::string an;
+      std::vector<int64_t> ints;
+      int64_t iv = 0;
+      bool has_i = false;
+      while (!a.at_end()) {
+        const uint64_t t2 = a.varint();
+        const int f2 = (int)(t2 >> 3), w2 = (int)(t2 & 7);
+        if (f2 == 1 && w2 == 2) { Reader d = a.sub(); an.assign((const char*)d.p, (size_t)(d.end - d.p)); }
+        else if (f2 == 3 && w2 == 0) { iv = (int64_t)a.varint(); has_i = true; }
+        else if (f2 == 8 && w2 == 2) { Reader d = a.sub(); while (!d.at_end()) ints.push_back((int64_t)d.varint()); }
+        else if (f2 == 8 && w2 == 0) ints.push_back((int64_t)a.varint());
+        else a.skip(w2);
+      }
+      if (!a.ok) return false;
+      if (an == "strides" && !ints.empty()) c.stride = ints[0];
+      else if (an == "dilations" && !ints.empty()) c.dilation = ints[0];
+      else if (an == "group" && has_i) c.group = iv;
+      else if (an == "pads" && ints.size() >= 2) { c.pad_l = ints[0]; c.pad_r = ints[ints.size() / 2]; has_pads = true; }
+    } else {
+      r.skip(wire);
+    }
+  }
+  (void)has_pads;
+  if (!r.ok) return false;
+  m->n_nodes++;
+  if ((op == "Conv" || op == "ConvTranspose") && inputs.size() >= 2) {
+    c.op = op;
+    c.weight = inputs[1];
+    m->conv_by_weight[c.weight] = c;
+  }
+  return true;
+}
+
+int parse_model(piper_hip_onnx* m) {
+  Reader r{m->data, m->data + m->size};
+  bool have_graph = false;
+  while (!r.at_end()) {
+    const uint64_t tag = r.varint();
+    const int field = (int)(tag >> 3), wire = (int)(tag & 7);
+    if (field == 1 && wire == 0) {
+      m->ir_version = (int64_t)r.varint();
+    } else if (field == 8 && wire == 2) {  // OperatorSetIdProto{1 domain, 2 version}: keep the default-domain version
+      Reader o = r.sub();
+      std::string domain;
+      int64_t ver = 0;
+      while (!o.at_end()) {
+        const uint64_t t2 = o.varint();
+        if ((t2 >> 3) == 1 && (t2 & 7) == 2) { Reader d = o.sub(); domain.assign((const char*)d.p, (size_t)(d.end - d.p)); }
+        else if ((t2 >> 3) == 2 && (t2 & 7) == 0) ver = (int64_t)o.varint();
+        else o.skip((int)(t2 & 7));
+      }
+      if (domain.empty() || domain == "ai.onnx") m->opset = ver;
+    } else if (field == 7 && wire == 2) {
+      Reader g = r.sub();
+      have_graph = true;
+      while (!g.at_end()) {
+        const uint64_t t2 = g.varint();
+        const int f2 = (int)(t2 >> 3), w2 = (int)(t2 & 7);
+        if (f2 == 1 && w2 == 2) {
+          if (!parse_node(g.sub(), m)) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: malformed NodeProto");
+        } else if (f2 == 5 && w2 == 2) {
+          Tensor t;
+          if (!parse_tensor(g.sub(), t)) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: malformed TensorProto");
+          m->by_name[t.name] = (int)m->tensors.size();
+          m->tensors.push_back(std::move(t));
+        } else {
+          g.skip(w2);
+        }
+      }
+      if (!g.ok) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: malformed GraphProto");
+    } else {
+      r.skip(wire);
+    }
+  }
+  if (!r.ok) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: malformed ModelProto");
+  if (!have_graph) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: no graph in model");
+  return PIPER_HIP_OK;
+}
+
+const Tensor* find(const piper_hip_onnx* m, const std::string& name) {
+  auto it = m->by_name.find(name);
+  return it == m->by_name.end() ? nullptr : &m->tensors[it->second];
+}
+
+// floats of a FLOAT tensor (raw little-endian or float_data), TensorValue.swift:45-116
+int read_floats(const Tensor& t, float* dst, size_t n) {
+  if (t.dtype != 1) PH_FAIL(PIPER_HIP_ERR_TYPE, "onnx: initializer '%s' has data_type %d, expected FLOAT(1)", t.name.c_str(), t.dtype);
+  if ((int64_t)n != t.count()) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: initializer '%s' has %lld elements, expected %zu", t.name.c_str(), (long long)t.count(), n);
+  if (t.raw_len) {
+    if (t.raw_len != n * 4) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: initializer '%s' raw_data is %zu bytes, expected %zu", t.name.c_str(), t.raw_len, n * 4);
+    memcpy(dst, t.raw, n * 4);
+  } else if (t.fdat_len) {
+    if (t.fdat_len != n * 4) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: initializer '%s' float_data is %zu bytes, expected %zu", t.name.c_str(), t.fdat_len, n * 4);
+    memcpy(dst, t.fdat, n * 4);
+  } else if (t.floats_unpacked.size() == n) {
+    memcpy(dst, t.floats_unpacked.data(), n * 4);
+  } else if (n != 0) {
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: initializer '%s' carries no data (external data is not supported)", t.name.c_str());
+  }
+  return PIPER_HIP_OK;
+}
+
+std::string fmt(const char* f, int a, int b = 0) {
+  char buf[160];
+  snprintf(buf, sizeof buf, f, a, b);
+  return buf;
+}
+
+struct BlobFill {
+  const piper_hip_onnx* m;
+  float* blob;
+  int rc;
+  std::vector<float> g, v;
+};
+
+void fill_visit(const piper_tensor_desc* d, void* user) {
+  BlobFill* b = (BlobFill*)user;
+  if (b->rc) return;
+  const std::string name = d->name;
+  float* dst = b->blob + d->offset;
+  if (const Tensor* t = find(b->m, name)) {
+    // shape check: same element count and, when ranks agree, the same dims
+    if ((int)t->dims.size() == d->rank)
+      for (int i = 0; i < d->rank; i++)
+        if (t->dims[i] != d->shape[i]) {
+          set_error("onnx: initializer '%s' dim %d is %lld, the voice geometry expects %lld", d->name, i, (long long)t->dims[i], d->shape[i]);
+          b->rc = PIPER_HIP_ERR_SHAPE;
+          return;
+        }
+    b->rc = read_floats(*t, dst, d->count);
+    return;
+  }
+  // weight norm left in the export: w = g · v / ‖v‖ over everything but dim 0
+  const Tensor* tg = find(b->m, name + "_g");
+  const Tensor* tv = find(b->m, name + "_v");
+  if (tg && tv && d->shape[0] > 0 && tg->count() == d->shape[0]) {
+    b->g.resize((size_t)d->shape[0]);
+    b->v.resize(d->count);
+    if ((b->rc = read_floats(*tg, b->g.data(), b->g.size()))) return;
+    if ((b->rc = read_floats(*tv, b->v.data(), d->count))) return;
+    const size_t per = d->count / (size_t)d->shape[0];
+    for (long long r = 0; r < d->shape[0]; r++) {
+      double ss = 0.0;
+      for (size_t i = 0; i < per; i++) ss += (double)b->v[r * per + i] * b->v[r * per + i];
+      const float scale = (float)(b->g[r] / std::sqrt(ss));
+      for (size_t i = 0; i < per; i++) dst[r * per + i] = b->v[r * per + i] * scale;
+    }
+    return;
+  }
+  set_error("onnx: initializer '%s' not found (nor %s_g/%s_v)", d->name, d->name, d->name);
+  b->rc = PIPER_HIP_ERR_ARG;
+}
+
+}  // namespace
+
+PH_EXPORT int piper_hip_onnx_open_memory(const void* data, size_t size, piper_hip_onnx** out) {
+  if (!data || !out) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx_open_memory: null argument");
+  std::unique_ptr<piper_hip_onnx> m(new piper_hip_onnx());
+  m->owned.assign((const uint8_t*)data, (const uint8_t*)data + size);
+  m->data = m->owned.data();
+  m->size = size;
+  int rc = parse_model(m.get());
+  if (rc) return rc;
+  *out = m.release();
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_onnx_open(const char* path, piper_hip_onnx** out) {
+  if (!path || !out) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx_open: null argument");
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx_open: cannot open '%s'", path);
+  struct stat st;
+  if (fstat(fd, &st) != 0 || st.st_size <= 0) { close(fd); PH_FAIL(PIPER_HIP_ERR_ARG, "onnx_open: cannot stat '%s'", path); }
+  void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);  // 60–110 MB voices: map, do not copy
+  close(fd);
+  if (map == MAP_FAILED) PH_FAIL(PIPER_HIP_ERR_ALLOC, "onnx_open: mmap of '%s' failed", path);
+  std::unique_ptr<piper_hip_onnx> m(new piper_hip_onnx());
+  m->map = map; m->map_len = (size_t)st.st_size;
+  m->data = (const uint8_t*)map; m->size = (size_t)st.st_size;
+  int rc = parse_model(m.get());
+  if (rc) { munmap(map, m->map_len); return rc; }
+  *out = m.release();
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT void piper_hip_onnx_close(piper_hip_onnx* m) {
+  if (!m) return;
+  if (m->map) munmap(m->map, m->map_len);
+  delete m;
+}
+
+PH_EXPORT int piper_hip_onnx_counts(const piper_hip_onnx* m, int64_t* ir_version, int64_t* opset, int* n_nodes, int* n_initializers) {
+  if (!m) PH_FAIL(PIPER_HIP_ERR_ARG, "null model");
+  if (ir_version) *ir_version = m->ir_version;
+  if (opset) *opset = m->opset;
+  if (n_nodes) *n_nodes = m->n_nodes;
+  if (n_initializers) *n_initializers = (int)m->tensors.size();
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_onnx_initializer(const piper_hip_onnx* m, int index, piper_hip_onnx_tensor_info* out) {
+  if (!m || !out) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (index < 0 || index >= (int)m->tensors.size()) PH_FAIL(PIPER_HIP_ERR_ARG, "initializer index %d out of range", index);
+  const Tensor& t = m->tensors[index];
+  memset(out, 0, sizeof *out);
+  snprintf(out->name, sizeof out->name, "%s", t.name.c_str());
+  out->data_type = t.dtype;
+  out->rank = (int32_t)t.dims.size();
+  for (int i = 0; i < out->rank && i < 8; i++) out->dims[i] = t.dims[i];
+  out->count = t.count();
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_onnx_find(const piper_hip_onnx* m, const char* name) {
+  if (!m || !name) return -1;
+  auto it = m->by_name.find(name);
+  return it == m->by_name.end() ? -1 : it->second;
+}
+
+PH_EXPORT int piper_hip_onnx_read_f32(const piper_hip_onnx* m, int index, float* dst, size_t n) {
+  if (!m || !dst) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (index < 0 || index >= (int)m->tensors.size()) PH_FAIL(PIPER_HIP_ERR_ARG, "initializer index %d out of range", index);
+  return read_floats(m->tensors[index], dst, n);
+}
+
+PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voice_config* cfg) {
+  if (!m || !cfg) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  memset(cfg, 0, sizeof *cfg);
+  auto need = [&](const std::string& name, size_t rank) -> const Tensor* {
+    const Tensor* t = find(m, name);
+    if (!t) t = find(m, name + "_v");  // weight norm left in
+    if (!t) { set_error("onnx: not a Piper VITS voice: initializer '%s' missing", name.c_str()); return nullptr; }
+    if (t->dims.size() != rank) { set_error("onnx: initializer '%s' has rank %zu, expected %zu", name.c_str(), t->dims.size(), rank); return nullptr; }
+    return t;
+  };
+  auto has = [&](const std::string& name) { return find(m, name) || find(m, name + "_v"); };
+  const Tensor* t;
+  if (!(t = need("enc_p.emb.weight", 2))) return PIPER_HIP_ERR_ARG;
+  cfg->n_vocab = (int32_t)t->dims[0];
+  cfg->hidden = (int32_t)t->dims[1];
+  while (has(fmt("enc_p.encoder.attn_layers.%d.conv_q.weight", cfg->n_layers))) cfg->n_layers++;
+  // [1, 2w+1, d] in a VITS export (one shared relative-position head); [2w+1, d] accepted too
+  t = find(m, "enc_p.encoder.attn_layers.0.emb_rel_k");
+  if (!t || t->dims.size() < 2 || t->dims.size() > 3)
+    PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: not a Piper VITS voice: 'enc_p.encoder.attn_layers.0.emb_rel_k' missing or not rank 2/3");
+  {
+    const int64_t rows = t->dims[t->dims.size() - 2], d = t->dims[t->dims.size() - 1];
+    cfg->window = (int32_t)((rows - 1) / 2);
+    cfg->n_heads = d > 0 ? (int32_t)(cfg->hidden / d) : 0;
+  }
+  if (!(t = need("enc_p.encoder.ffn_layers.0.conv_1.weight", 3))) return PIPER_HIP_ERR_ARG;
+  cfg->ffn = (int32_t)t->dims[0];
+  cfg->ffn_kernel = (int32_t)t->dims[2];
+  if (!(t = need("enc_p.proj.weight", 3))) return PIPER_HIP_ERR_ARG;
+  cfg->inter = (int32_t)(t->dims[0] / 2);
+  while (has(fmt("flow.flows.%d.pre.weight", 2 * cfg->n_flows))) cfg->n_flows++;
+  while (has(fmt("flow.flows.0.enc.in_layers.%d.weight", cfg->wn_layers))) cfg->wn_layers++;
+  if (!(t = need("flow.flows.0.enc.in_layers.0.weight", 3))) return PIPER_HIP_ERR_ARG;
+  cfg->wn_kernel = (int32_t)t->dims[2];
+  if (!(t = need("dec.conv_pre.weight", 3))) return PIPER_HIP_ERR_ARG;
+  cfg->up_initial = (int32_t)t->dims[0];
+  while (cfg->n_ups < PIPER_HIP_MAX_UPS && has(fmt("dec.ups.%d.weight", cfg->n_ups))) {
+    const std::string wn = fmt("dec.ups.%d.weight", cfg->n_ups);
+    if (!(t = need(wn, 3))) return PIPER_HIP_ERR_ARG;
+    cfg->up_kernels[cfg->n_ups] = (int32_t)t->dims[2];
+    auto it = m->conv_by_weight.find(wn);
+    // the stride lives on the ConvTranspose node; HiFi-GAN's convention K = 2·stride is the fallback
+    cfg->up_rates[cfg->n_ups] = it != m->conv_by_weight.end() ? (int32_t)it->second.stride : (int32_t)(t->dims[2] / 2);
+    cfg->n_ups++;
+  }
+  if (has(fmt("dec.ups.%d.weight", cfg->n_ups))) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "onnx: more than %d upsampling stages", PIPER_HIP_MAX_UPS);
+  cfg->resblock_type = has("dec.resblocks.0.convs1.0.weight") ? 1 : 2;
+  const char* first = cfg->resblock_type == 1 ? "dec.resblocks.%d.convs1.%d.weight" : "dec.resblocks.%d.convs.%d.weight";
+  int n_resblocks = 0;
+  while (has(fmt(first, n_resblocks, 0))) n_resblocks++;
+  if (cfg->n_ups <= 0 || n_resblocks % cfg->n_ups) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: %d resblocks over %d stages", n_resblocks, cfg->n_ups);
+  cfg->n_rb = n_resblocks / cfg->n_ups;
+  if (cfg->n_rb > PIPER_HIP_MAX_RB) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "onnx: %d resblocks per stage (max %d)", cfg->n_rb, PIPER_HIP_MAX_RB);
+  while (cfg->rb_n_dil < 3 && has(fmt(first, 0, cfg->rb_n_dil))) cfg->rb_n_dil++;
+  for (int j = 0; j < cfg->n_rb; j++) {
+    if (!(t = need(fmt(first, j, 0), 3))) return PIPER_HIP_ERR_ARG;
+    cfg->rb_kernels[j] = (int32_t)t->dims[2];
+    for (int d = 0; d < cfg->rb_n_dil; d++) {
+      auto it = m->conv_by_weight.find(fmt(first, j, d));
+      static const int fallback1[3] = {1, 3, 5}, fallback2[3] = {1, 3, 5};
+      cfg->rb_dilations[j][d] = it != m->conv_by_weight.end() ? (int32_t)it->second.dilation
+                                                              : (cfg->resblock_type == 1 ? fallback1[d] : fallback2[d]);
+    }
+  }
+  cfg->sample_rate = 22050;  // lives in the voice's .onnx.json (piper_hip_piper_json), not in the graph
+  size_t n = 0;
+  return piper_hip_voice_blob_floats(cfg, &n);  // validates the geometry
+}
+
+PH_EXPORT int piper_hip_onnx_build_blob(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats) {
+  if (!m || !cfg || !host_blob) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  size_t need = 0;
+  int rc = piper_hip_voice_blob_floats(cfg, &need);
+  if (rc) return rc;
+  if (n_floats != need) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx_build_blob: blob has %zu floats, the geometry needs %zu", n_floats, need);
+  BlobFill b{m, host_blob, PIPER_HIP_OK, {}, {}};
+  piper_hip_layout_walk(cfg, fill_visit, &b);
+  return b.rc;
+}
+
+// ---- the voice's `.onnx.json` (PiperConfig.swift:3-47): the few numbers this library needs, by key
+namespace {
+bool json_number(const std::string& s, const char* key, double* out, size_t from = 0, size_t* at = nullptr) {
+  const std::string k = std::string("\"") + key + "\"";
+  size_t p = s.find(k, from);
+  if (p == std::string::npos) return false;
+  p = s.find(':', p + k.size());
+  if (p == std::string::npos) return false;
+  char* endp = nullptr;
+  const double v = strtod(s.c_str() + p + 1, &endp);
+  if (endp == s.c_str() + p + 1) return false;
+  *out = v;
+  if (at) *at = p;
+  return true;
+}
+}  // namespace
+
+PH_EXPORT int piper_hip_piper_json(const char* json_text, piper_hip_piper_json_info* out) {
+  if (!json_text || !out) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  const std::string s(json_text);
+  memset(out, 0, sizeof *out);
+  double v = 0;
+  const size_t audio = s.find("\"audio\"");
+  if (audio == std::string::npos || !json_number(s, "sample_rate", &v, audio)) PH_FAIL(PIPER_HIP_ERR_ARG, "piper json: audio.sample_rate missing");
+  out->sample_rate = (int32_t)v;
+  if (!json_number(s, "num_symbols", &v)) PH_FAIL(PIPER_HIP_ERR_ARG, "piper json: num_symbols missing");
+  out->num_symbols = (int32_t)v;
+  out->num_speakers = json_number(s, "num_speakers", &v) ? (int32_t)v : 1;
+  const size_t inf = s.find("\"inference\"");
+  out->noise_scale = 0.667f; out->length_scale = 1.0f; out->noise_w = 0.8f;  // Piper defaults
+  if (inf != std::string::npos) {
+    if (json_number(s, "noise_scale", &v, inf)) out->noise_scale = (float)v;
+    if (json_number(s, "length_scale", &v, inf)) out->length_scale = (float)v;
+    if (json_number(s, "noise_w", &v, inf)) out->noise_w = (float)v;
+  }
+  return PIPER_HIP_OK;
+}

@@ -92,6 +92,16 @@ class TensorInfo(C.Structure):
                 ("fan_in", C.c_int64), ("offset", C.c_uint64), ("count", C.c_uint64)]
 
 
+class OnnxTensorInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("data_type", C.c_int32), ("rank", C.c_int32), ("dims", C.c_int64 * 8),
+                ("count", C.c_int64)]
+
+
+class PiperJsonInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("num_symbols", C.c_int32), ("num_speakers", C.c_int32),
+                ("noise_scale", C.c_float), ("length_scale", C.c_float), ("noise_w", C.c_float)]
+
+
 class Utterance(C.Structure):
     _fields_ = [("phoneme_ids", c_i64p), ("t", C.c_int32), ("durations", c_i32p), ("noise", c_f32p),
                 ("noise_scale", C.c_float)]
@@ -155,6 +165,17 @@ _PROTOS = {
                                               C.POINTER(C.c_int)]),
     "piper_hip_voice_synthetic_blob": (C.c_int, [C.POINTER(VoiceConfig), C.c_uint64, c_f32p, C.c_size_t]),
     "piper_hip_voice_create": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_vp, C.c_int, C.POINTER(c_vp)]),
+    "piper_hip_onnx_open": (C.c_int, [C.c_char_p, C.POINTER(c_vp)]),
+    "piper_hip_onnx_open_memory": (C.c_int, [c_vp, C.c_size_t, C.POINTER(c_vp)]),
+    "piper_hip_onnx_close": (None, [c_vp]),
+    "piper_hip_onnx_counts": (C.c_int, [c_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]),
+    "piper_hip_onnx_initializer": (C.c_int, [c_vp, C.c_int, C.POINTER(OnnxTensorInfo)]),
+    "piper_hip_onnx_find": (C.c_int, [c_vp, C.c_char_p]),
+    "piper_hip_onnx_read_f32": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_size_t]),
+    "piper_hip_onnx_infer_config": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
+    "piper_hip_onnx_build_blob": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
+    "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
     "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
@@ -525,6 +546,76 @@ def synthetic_blob(cfg, seed=1234):
     blob = np.empty(n, np.float32)
     _check(load_library().piper_hip_voice_synthetic_blob(C.byref(cfg), seed, blob.ctypes.data_as(c_f32p), n))
     return blob
+
+
+class OnnxModel:
+    """A Piper `.onnx` opened by the library's own protobuf reader (host-only; the role of PiperONNX.ONNXLoader)."""
+
+    def __init__(self, path=None, data=None):
+        self.lib = load_library()
+        h = c_vp()
+        if path is not None:
+            _check(self.lib.piper_hip_onnx_open(str(path).encode(), C.byref(h)))
+        else:
+            buf = (C.c_char * len(data)).from_buffer_copy(data)
+            _check(self.lib.piper_hip_onnx_open_memory(buf, len(data), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.piper_hip_onnx_close(self.h)
+            self.h = None
+
+    def counts(self):
+        ir, op, nn, ni = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        _check(self.lib.piper_hip_onnx_counts(self.h, C.byref(ir), C.byref(op), C.byref(nn), C.byref(ni)))
+        return dict(ir_version=ir.value, opset=op.value, nodes=nn.value, initializers=ni.value)
+
+    def initializer(self, index):
+        info = OnnxTensorInfo()
+        _check(self.lib.piper_hip_onnx_initializer(self.h, index, C.byref(info)))
+        return dict(name=info.name.decode(), data_type=info.data_type, dims=[int(d) for d in info.dims[:info.rank]],
+                    count=int(info.count))
+
+    def find(self, name):
+        return int(self.lib.piper_hip_onnx_find(self.h, name.encode()))
+
+    def read_f32(self, index):
+        n = self.initializer(index)["count"]
+        out = np.empty(n, np.float32)
+        _check(self.lib.piper_hip_onnx_read_f32(self.h, index, out.ctypes.data_as(c_f32p), n))
+        return out
+
+    def infer_config(self):
+        cfg = VoiceConfig()
+        _check(self.lib.piper_hip_onnx_infer_config(self.h, C.byref(cfg)))
+        return cfg
+
+    def build_blob(self, cfg):
+        blob = np.empty(blob_floats(cfg), np.float32)
+        _check(self.lib.piper_hip_onnx_build_blob(self.h, C.byref(cfg), blob.ctypes.data_as(c_f32p), blob.size))
+        return blob
+
+
+def load_voice(onnx_path, json_path=None):
+    """(cfg, blob, json info) of a Piper voice: `<voice>.onnx` + `<voice>.onnx.json` (PiperVoices layout)."""
+    m = OnnxModel(onnx_path)
+    try:
+        cfg = m.infer_config()
+        info = None
+        jp = json_path or (str(onnx_path) + ".json")
+        if os.path.exists(jp):
+            info = piper_json(open(jp, "r", encoding="utf-8").read())
+            cfg.sample_rate = info.sample_rate
+        return cfg, m.build_blob(cfg), info
+    finally:
+        m.close()
+
+
+def piper_json(text):
+    info = PiperJsonInfo()
+    _check(load_library().piper_hip_piper_json(text.encode("utf-8"), C.byref(info)))
+    return info
 
 
 class HipRuntime:

@@ -287,3 +287,20 @@ def test_bf16_generator_snr(quality, voices, backend):
         assert np.array_equal(rt.synthesize(ids, dur, noise, 0.667), fp32)
     finally:
         rt.close()
+
+
+def test_voice_loaded_from_onnx_file(backend, voices, tmp_path):
+    """`.onnx` (written by tests/onnx_writer.py) → library's own loader → voice → waveform == oracle on the source blob."""
+    import onnx_writer as ow
+    cfg, blob = voices["medium"]
+    lay = [dict(name=t["name"], offset=t["offset"], count=t["count"], shape=list(t["shape"])) for t in ph.blob_layout(cfg)]
+    path = tmp_path / "voice.onnx"
+    path.write_bytes(ow.piper_voice_onnx(cfg, blob, lay, weight_norm={"dec.ups.1.weight"}))
+    cfg2, blob2, _ = ph.load_voice(path)
+    rt = ph.HipRuntime(backend, cfg2, blob2)
+    try:
+        ids, dur = kd.FIXTURE_IDS, [3] * 14
+        noise = kd.sym(SD + 600, (cfg.inter, 42), 1.7320508)
+        assert_close(rt.synthesize(ids, dur, noise, 0.667), orc.synthesize(cfg, blob, ids, dur, noise, 0.667), WAVE_TOL, "onnx voice")
+    finally:
+        rt.close()

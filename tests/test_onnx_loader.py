@@ -1,0 +1,129 @@
+"""ONNX loader (csrc/onnx_loader.cpp) against Piper-shaped files written by tests/onnx_writer.py.
+
+CPU-only. No Piper voice exists offline, so real-voice initializer naming is unpinned; what is pinned is the
+wire-format decoding, the geometry inference and the blob order (include/piper_hip_voice_layout.h)."""
+import json
+
+import numpy as np
+import pytest
+
+import onnx_writer as ow
+import piper_hip as ph
+
+
+def layout_dicts(cfg):
+    return [dict(name=t["name"], offset=t["offset"], count=t["count"], shape=list(t["shape"])) for t in ph.blob_layout(cfg)]
+
+
+CFG_FIELDS = ["n_vocab", "hidden", "n_heads", "n_layers", "ffn", "ffn_kernel", "window", "inter", "n_flows", "wn_layers",
+              "wn_kernel", "up_initial", "n_ups", "resblock_type", "n_rb", "rb_n_dil", "sample_rate"]
+
+
+def same_config(a, b):
+    for f in CFG_FIELDS:
+        assert getattr(a, f) == getattr(b, f), f
+    for u in range(a.n_ups):
+        assert a.up_rates[u] == b.up_rates[u] and a.up_kernels[u] == b.up_kernels[u]
+    for j in range(a.n_rb):
+        assert a.rb_kernels[j] == b.rb_kernels[j]
+        for d in range(a.rb_n_dil):
+            assert a.rb_dilations[j][d] == b.rb_dilations[j][d], (j, d)
+
+
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_onnx_roundtrip_bit_exact(quality, voices, tmp_path):
+    cfg, blob = voices[quality]
+    data = ow.piper_voice_onnx(cfg, blob, layout_dicts(cfg))
+    path = tmp_path / f"{quality}.onnx"
+    path.write_bytes(data)
+    (tmp_path / f"{quality}.onnx.json").write_text(json.dumps({
+        "audio": {"sample_rate": 22050, "quality": quality}, "espeak": {"voice": "en-gb"},
+        "inference": {"noise_scale": 0.667, "length_scale": 1.0, "noise_w": 0.8}, "phoneme_type": "espeak",
+        "phoneme_id_map": {"_": [0], "a": [14]}, "num_symbols": 256, "num_speakers": 1}))
+    m = ph.OnnxModel(path)
+    c = m.counts()
+    assert c["opset"] == 15 and c["ir_version"] == 8
+    assert c["initializers"] == len(ph.blob_layout(cfg)) + 1
+    same_config(m.infer_config(), cfg)
+    i = m.find("enc_p.encoder.attn_layers.0.conv_q.weight")  # the name the reference's parsing test looks up
+    assert i >= 0 and m.initializer(i)["dims"] == [cfg.hidden, cfg.hidden, 1] and m.initializer(i)["data_type"] == 1
+    assert m.find("no.such.tensor") == -1
+    m.close()
+    cfg2, blob2, info = ph.load_voice(path)
+    same_config(cfg2, cfg)
+    assert np.array_equal(blob2, blob)  # every initializer landed at its layout offset, bit for bit
+    assert info.sample_rate == 22050 and info.num_symbols == 256 and abs(info.noise_w - 0.8) < 1e-7
+
+
+def test_onnx_weight_norm_is_folded(voices):
+    cfg, blob = voices["medium"]
+    wn = {"dec.resblocks.0.convs.0.weight", "flow.flows.0.enc.in_layers.1.weight", "dec.conv_pre.weight"}
+    m = ph.OnnxModel(data=ow.piper_voice_onnx(cfg, blob, layout_dicts(cfg), weight_norm=wn))
+    same_config(m.infer_config(), cfg)
+    out = m.build_blob(cfg)
+    m.close()
+    for t in layout_dicts(cfg):
+        a, b = out[t["offset"]:t["offset"] + t["count"]], blob[t["offset"]:t["offset"] + t["count"]]
+        if t["name"] in wn:
+            np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-9)
+        else:
+            assert np.array_equal(a, b), t["name"]
+
+
+def test_onnx_unpacked_float_encoding_and_read():
+    t = ow.tensor("w", [2, 3], np.arange(6, dtype=np.float32), "float_unpacked")
+    m = ph.OnnxModel(data=ow.model([ow.node("Relu", ["x"], ["y"])], [t]))
+    assert m.counts()["nodes"] == 1
+    assert np.array_equal(m.read_f32(0), np.arange(6, dtype=np.float32))
+    with pytest.raises(ph.ExecutionError):
+        m.infer_config()  # not a Piper voice
+    m.close()
+
+
+def test_onnx_errors(voices, tmp_path):
+    cfg, blob = voices["medium"]
+    with pytest.raises(ph.ExecutionError):
+        ph.OnnxModel(tmp_path / "missing.onnx")
+    with pytest.raises(ph.ExecutionError):
+        ph.OnnxModel(data=b"\x3a\xff\xff\xff\xff\x0f")  # graph length runs past the end of the buffer
+    lay = layout_dicts(cfg)
+    # a voice with one initializer missing: build_blob names it
+    short = [t for t in lay if t["name"] != "flow.flows.2.post.bias"]
+    inits_model = ow.piper_voice_onnx(cfg, blob, lay)
+    m = ph.OnnxModel(data=inits_model)
+    m.close()
+    data = ow.model([], [ow.tensor(t["name"], t["shape"], blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"])) for t in short])
+    m = ph.OnnxModel(data=data)
+    with pytest.raises(ph.ExecutionError) as e:
+        m.build_blob(cfg)
+    assert "flow.flows.2.post.bias" in str(e.value)
+    m.close()
+    # wrong dtype for a float tensor
+    bad = [ow.tensor(t["name"], t["shape"], blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"])) for t in lay[1:]]
+    bad.insert(0, ow.tensor(lay[0]["name"], lay[0]["shape"], np.zeros(lay[0]["shape"], np.int64)))
+    m = ph.OnnxModel(data=ow.model([], bad))
+    with pytest.raises(ph.TypeMismatch):
+        m.build_blob(cfg)
+    m.close()
+
+
+def test_piper_json_defaults_and_errors():
+    info = ph.piper_json('{"audio": {"sample_rate": 16000}, "num_symbols": 130}')
+    assert info.sample_rate == 16000 and info.num_speakers == 1 and abs(info.noise_scale - 0.667) < 1e-6
+    with pytest.raises(ph.ExecutionError):
+        ph.piper_json('{"num_symbols": 130}')
+
+
+def test_onnx_truncated_files_fail_cleanly():
+    """Every prefix of a valid model either parses or reports an error — the reader never runs past its buffer."""
+    t = [ow.tensor(f"w{i}", [4, 3], np.arange(12, dtype=np.float32) + i, enc) for i, enc in enumerate(["raw", "float_data", "float_unpacked"])]
+    data = ow.model([ow.node("Conv", ["x", "w0"], ["y"], [ow.attr_ints("strides", [2]), ow.attr_int("group", 1)])], t)
+    ok = 0
+    for n in range(1, len(data) + 1):
+        try:
+            m = ph.OnnxModel(data=data[:n])
+            m.close()
+            ok += 1
+        except ph.ExecutionError:
+            pass
+    assert ok >= 1  # at least the full file
