@@ -324,6 +324,10 @@ typedef struct {
 } piper_hip_piper_json_info;
 int piper_hip_piper_json(const char* json_text, piper_hip_piper_json_info* out);
 
+/* Waveform → 16-bit PCM / mono WAV (WavFileWriter.swift:20-30, 44-60): clamp to [−1,1], ×32767, truncate toward zero. */
+int piper_hip_pcm16_from_f32(const float* samples, size_t n, int16_t* pcm);
+int piper_hip_wav_write(const char* path, const float* samples, size_t n, int32_t sample_rate);
+
 /* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104). The duration
  * predictor is outside this library's scope, so per-id frame counts are supplied (the reference's own
  * `overrides` mechanism); `noise` is the "main" RandomNormalLike tensor [inter, F] injected by name

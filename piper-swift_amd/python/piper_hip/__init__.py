@@ -176,6 +176,8 @@ _PROTOS = {
     "piper_hip_onnx_infer_config": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
     "piper_hip_onnx_build_blob": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
     "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
+    "piper_hip_pcm16_from_f32": (C.c_int, [c_f32p, C.c_size_t, C.POINTER(C.c_int16)]),
+    "piper_hip_wav_write": (C.c_int, [C.c_char_p, c_f32p, C.c_size_t, C.c_int32]),
     "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
@@ -610,6 +612,18 @@ def load_voice(onnx_path, json_path=None):
         return cfg, m.build_blob(cfg), info
     finally:
         m.close()
+
+
+def pcm16(samples):
+    a = np.ascontiguousarray(samples, np.float32)
+    out = np.empty(a.size, np.int16)
+    _check(load_library().piper_hip_pcm16_from_f32(a.ctypes.data_as(c_f32p), a.size, out.ctypes.data_as(C.POINTER(C.c_int16))))
+    return out
+
+
+def wav_write(path, samples, sample_rate=22050):
+    a = np.ascontiguousarray(samples, np.float32)
+    _check(load_library().piper_hip_wav_write(str(path).encode(), a.ctypes.data_as(c_f32p), a.size, int(sample_rate)))
 
 
 def piper_json(text):

@@ -127,3 +127,20 @@ def test_onnx_truncated_files_fail_cleanly():
         except ph.ExecutionError:
             pass
     assert ok >= 1  # at least the full file
+
+
+def test_wav_writer_matches_reference_conversion(tmp_path):
+    """WavFileWriter.swift:20-30: clamp to [-1,1] in double, ×32767.0, truncate toward zero; RIFF/PCM16 mono header."""
+    import wave
+    x = np.concatenate([np.array([0.0, 1.0, -1.0, 1.5, -2.0, 0.99999, -0.99999, 3.0517578e-05, -3.0517578e-05, 0.5, -0.5], np.float32),
+                        np.random.RandomState(3).uniform(-1.2, 1.2, 70000).astype(np.float32)])
+    ref = np.trunc(np.clip(x.astype(np.float64), -1.0, 1.0) * 32767.0).astype(np.int16)
+    assert np.array_equal(ph.pcm16(x), ref)
+    p = tmp_path / "out.wav"
+    ph.wav_write(p, x, 22050)
+    with wave.open(str(p), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 22050, x.size)
+        assert np.array_equal(np.frombuffer(w.readframes(x.size), "<i2"), ref)
+    assert p.stat().st_size == 44 + 2 * x.size
+    with pytest.raises(ph.ExecutionError):
+        ph.wav_write(tmp_path / "no_such_dir" / "x.wav", x)
