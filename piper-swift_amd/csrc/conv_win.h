@@ -11,6 +11,8 @@ namespace ph {
 
 struct ConvWinArgs {
   const float* x = nullptr;     // fp32 [N][Cin][Lin]
+  const float* x2 = nullptr;    // both set: the input is ((x + x2) + x3) / 3 (HiFi-GAN MRF mean folded into the consumer)
+  const float* x3 = nullptr;
   const float* w4 = nullptr;    // fragment image (pack_conv_weights_win / pack_convt_weights_win)
   const float* bias = nullptr;  // [Cout] or null
   const float* res = nullptr;   // [N][Cout][y_len] added to the result, may be null
@@ -36,5 +38,10 @@ bool conv_win_eligible(int Cout, int Cin, int K, int dil, int padL, int Lin, int
 bool convt_win_eligible(int Cin, int Cout, int K, int stride, int pad, int Lin);
 
 int launch_conv_win(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs& a);
+// Up to kWinMulti independent convs of the SAME shape class (N, Cin, Cout, Lin, Lout, conv vs convT) in one launch — the
+// three ResBlocks of a HiFi-GAN stage differ only in kernel size, dilation, weights and buffers. One launch instead of
+// three short dependent-free ones: the blocks of all convs share the chip, and two launch boundaries disappear.
+constexpr int kWinMulti = 3;
+int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* convs, int count);
 
 }  // namespace ph

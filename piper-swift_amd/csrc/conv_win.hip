@@ -12,6 +12,9 @@
 //   3. when the problem has fewer 32×32 tiles than the chip has SIMDs, the block's waves split the contraction (KS = 2
 //      or 4 contiguous step ranges) and reduce in fixed order through LDS — deterministic, like conv_stream_kernel;
 //   4. epilogue: bias, residual, MRF mean, LeakyReLU, ConvTranspose scatter — loads first, masked stores after.
+#include <algorithm>
+#include <type_traits>
+
 #include "conv_win.h"
 
 namespace ph {
@@ -68,9 +71,14 @@ __global__ __launch_bounds__(kBT) void pack_convt_win_kernel(const float* __rest
 }
 
 // WM waves along rows × WN along columns × KS along the contraction; WM·WN·KS = 4. One 32×32 tile per wave.
+struct ConvWinMulti {
+  ConvWinArgs c[kWinMulti];
+};
+
 template <int WM, int WN, int KS>
-__global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinArgs p) {
+__global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi, int batch) {
   extern __shared__ __attribute__((aligned(16))) float win[];  // [Cin][Wp] + dump float4; reused for the K-split reduction
+  const ConvWinArgs& p = multi.c[blockIdx.z / batch];  // wave-uniform: which of the launch's convs this block works on
   static_assert(WM * WN * KS == 4, "4 waves per block");
   constexpr int NBC = WN * 32;
   const int lane = threadIdx.x & 63;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinArgs p) {
   const bool ct = p.ct_stride > 0;
   const int taps = ct ? p.K / p.ct_stride : p.K;
   const int C2 = p.Cin >> 1;
-  const int n = blockIdx.z;
+  const int n = blockIdx.z % batch;
   const int nb0 = blockIdx.x * NBC;
   const int mt = blockIdx.y * WM + wm;
   const int off_min = ct ? -(taps - 1) : -p.padL;
@@ -105,25 +113,30 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinArgs p) {
   for (int d = 0; d < kRA - 1; d++) load_a(d, d);
 
   // ---- stage the window: rows by wave, 256 positions (64 lanes × float4) per wave instruction
-  {
-    const float* xb = p.x + (int64_t)n * p.Cin * p.Lin;
-    constexpr int kStage = 16;
+  auto stage = [&](auto avg_tag) {
+    constexpr bool AVG = decltype(avg_tag)::value;
+    constexpr int kStage = AVG ? 5 : 16;  // float4 loads in flight per lane: 16, or 5 × 3 sources
+    const int64_t xoff = (int64_t)n * p.Cin * p.Lin;
+    const float* xb = p.x + xoff;
+    const float* xb2 = AVG ? p.x2 + xoff : nullptr;
+    const float* xb3 = AVG ? p.x3 + xoff : nullptr;
     const int W4 = Wp >> 2;              // float4s per row
     const int WCH = (W4 + 63) >> 6;
     const int dump = p.Cin * Wp;         // lanes past the row end / rows past Cin store here (keeps the loads unconditional)
     int row = wave, chunk = 0;
     while (row < p.Cin) {
-      float4 t[kStage];
+      float4 t[kStage], t2[AVG ? kStage : 1], t3[AVG ? kStage : 1];
       int dst[kStage];
+      bool in[kStage];
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
         const int rr = min(row, p.Cin - 1);
         const int i4 = chunk * 64 + lane;
         const int pos = ga + 4 * i4;     // multiple of 4, rows are multiples of 4 long: all-in or all-out
-        const bool inb = pos >= 0 && pos < p.Lin;
-        float4 v = *(const float4*)(xb + (int64_t)rr * p.Lin + (inb ? pos : 0));
-        if (!inb) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        t[q] = v;
+        in[q] = pos >= 0 && pos < p.Lin;
+        const int64_t off = (int64_t)rr * p.Lin + (in[q] ? pos : 0);
+        t[q] = *(const float4*)(xb + off);
+        if constexpr (AVG) { t2[q] = *(const float4*)(xb2 + off); t3[q] = *(const float4*)(xb3 + off); }
         dst[q] = (row < p.Cin && i4 < W4) ? rr * Wp + 4 * i4 : dump;
         chunk++;
         const bool wrap = chunk == WCH;
@@ -133,11 +146,18 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinArgs p) {
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
         float4 v = t[q];
+        if constexpr (AVG) {  // ((x + x2) + x3) / 3: the association of the graph's Add, Add, Div
+          v.x = ((v.x + t2[q].x) + t3[q].x) / 3.0f; v.y = ((v.y + t2[q].y) + t3[q].y) / 3.0f;
+          v.z = ((v.z + t2[q].z) + t3[q].z) / 3.0f; v.w = ((v.w + t2[q].w) + t3[q].w) / 3.0f;
+        }
         v.x = lrelu1(v.x, p.pro_alpha); v.y = lrelu1(v.y, p.pro_alpha); v.z = lrelu1(v.z, p.pro_alpha); v.w = lrelu1(v.w, p.pro_alpha);
+        if (!in[q]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         *(float4*)(win + dst[q]) = v;
       }
     }
-  }
+  };
+  if (p.x2) stage(std::true_type{});
+  else stage(std::false_type{});
   __syncthreads();
 
   f32x16 acc;
@@ -252,13 +272,13 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinArgs p) {
 }
 
 template <int WM, int WN, int KS>
-int launch_inst(hipStream_t s, const ConvWinArgs& a, dim3 grid, size_t lds) {
+int launch_inst(hipStream_t s, const ConvWinMulti& a, int batch, dim3 grid, size_t lds) {
   static bool raised = false;
   if (lds > 64 * 1024 && !raised) {
     (void)hipFuncSetAttribute((const void*)conv_win_kernel<WM, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     raised = true;
   }
-  hipLaunchKernelGGL((conv_win_kernel<WM, WN, KS>), grid, dim3(kBT), lds, s, a);
+  hipLaunchKernelGGL((conv_win_kernel<WM, WN, KS>), grid, dim3(kBT), lds, s, a, batch);
   return PIPER_HIP_OK;
 }
 
@@ -313,36 +333,51 @@ bool convt_win_eligible(int Cin, int Cout, int K, int stride, int pad, int Lin) 
   return K % stride == 0 && K - stride == 2 * pad;
 }
 
-int launch_conv_win(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs& a) {
+int launch_conv_win(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs& a) { return launch_conv_win_multi(ctx, s, &a, 1); }
+
+int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* convs, int count) {
+  if (count < 1 || count > kWinMulti) PH_FAIL(PIPER_HIP_ERR_ARG, "conv_win: %d convs in one launch (1..%d)", count, kWinMulti);
+  const ConvWinArgs& a = convs[0];
   if (a.N <= 0 || a.Lout <= 0) return PIPER_HIP_OK;
   const WinGeom g = geom(a);
-  const int64_t tiles = (int64_t)g.MT * ceil_div(a.Lout, 32) * a.N;
+  int reach = g.reach, Sp_min = padded_steps_win(a.Cin, g.taps);
+  for (int i = 1; i < count; i++) {
+    const ConvWinArgs& b = convs[i];
+    if (b.N != a.N || b.Cin != a.Cin || b.Cout != a.Cout || b.Lin != a.Lin || b.Lout != a.Lout || b.ct_stride != a.ct_stride)
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv_win: convs of one launch must share N, Cin, Cout, Lin, Lout and kind");
+    const WinGeom gb = geom(b);
+    reach = std::max(reach, gb.reach);
+    Sp_min = std::min(Sp_min, padded_steps_win(b.Cin, gb.taps));
+  }
+  const int64_t tiles = (int64_t)g.MT * ceil_div(a.Lout, 32) * a.N * count;
   const int64_t simds = 4 * (int64_t)ctx->num_cus;
   // split the contraction while there are fewer tiles than SIMDs (each split wave keeps ≥ 16 steps)
-  const int Sp = padded_steps_win(a.Cin, g.taps);
   int KS = tiles >= simds ? 1 : (2 * tiles >= simds ? 2 : 4);
-  while (KS > 1 && Sp / KS < 16) KS >>= 1;
+  while (KS > 1 && Sp_min / KS < 16) KS >>= 1;
   // candidates in order of preference: the wanted K-split first; waves along rows before columns (they then share the
   // staged window and nothing else); a single row tile (C = 32) puts the waves side by side along the columns
   static const int cand[6][3] = {{4, 1, 1}, {2, 2, 1}, {1, 4, 1}, {2, 1, 2}, {1, 2, 2}, {1, 1, 4}};
-  int WM = 0, WN = 0, best = -1;
+  int best = -1;
   static const char* force = getenv("PIPER_HIP_WIN_CFG");  // tuning hook: "WM,WN,KS"
   int fm = 0, fn = 0, fk = 0;
   const bool forced = force && sscanf(force, "%d,%d,%d", &fm, &fn, &fk) == 3;
   for (int pass = 0; pass < 3 && best < 0; pass++)  // 0: forced, 1: wanted KS, 2: anything that fits
     for (int i = 0; i < 6 && best < 0; i++) {
       const int m = cand[i][0], nn = cand[i][1], k = cand[i][2];
-      if (g.per_phase % m || (k > 1 && Sp / k < 16) || lds_bytes(a.Cin, nn, g.reach, k, m * nn) > 160 * 1024) continue;
+      if (g.per_phase % m || (k > 1 && Sp_min / k < 16) || lds_bytes(a.Cin, nn, reach, k, m * nn) > 160 * 1024) continue;
       if (pass == 0 && !(forced && m == fm && nn == fn && k == fk)) continue;
       if (pass == 1 && k != KS) continue;
       best = i;
     }
-  if (best < 0) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_win: no configuration fits (Cin=%d reach=%d rows/phase=%d)", a.Cin, g.reach, g.per_phase);
-  WM = cand[best][0]; WN = cand[best][1]; KS = cand[best][2];
-  const size_t lds = lds_bytes(a.Cin, WN, g.reach, KS, WM * WN);
-  const dim3 grid((unsigned)ceil_div(a.Lout, WN * 32), (unsigned)ceil_div(g.MT, WM), (unsigned)a.N);
+  if (best < 0) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_win: no configuration fits (Cin=%d reach=%d rows/phase=%d)", a.Cin, reach, g.per_phase);
+  const int WM = cand[best][0], WN = cand[best][1];
+  KS = cand[best][2];
+  const size_t lds = lds_bytes(a.Cin, WN, reach, KS, WM * WN);
+  const dim3 grid((unsigned)ceil_div(a.Lout, WN * 32), (unsigned)ceil_div(g.MT, WM), (unsigned)(a.N * count));
+  ConvWinMulti multi;
+  for (int i = 0; i < kWinMulti; i++) multi.c[i] = convs[i < count ? i : 0];
 #define PH_WIN_CASE(M, N_, K_) \
-  if (WM == M && WN == N_ && KS == K_) launch_inst<M, N_, K_>(s, a, grid, lds); else
+  if (WM == M && WN == N_ && KS == K_) launch_inst<M, N_, K_>(s, multi, a.N, grid, lds); else
   PH_WIN_CASE(4, 1, 1) PH_WIN_CASE(2, 2, 1) PH_WIN_CASE(1, 4, 1) PH_WIN_CASE(2, 1, 2) PH_WIN_CASE(1, 2, 2) PH_WIN_CASE(1, 1, 4)
   PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_win: no instance for WM=%d WN=%d KS=%d", WM, WN, KS);
 #undef PH_WIN_CASE

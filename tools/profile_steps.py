@@ -15,6 +15,7 @@ ap.add_argument("--factor", type=int, default=8)
 ap.add_argument("--quality", default="medium")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--precision", default="f32")
+ap.add_argument("--batch", type=int, default=1)
 args = ap.parse_args()
 b = ph.HipBackend(0)
 cfg = ph.voice_config(args.quality)
@@ -22,7 +23,11 @@ rt = ph.HipRuntime(b, cfg, ph.synthetic_blob(cfg, 1234))
 rt.set_precision(args.precision)
 ids = kd.FIXTURE_IDS * args.factor
 dur = [3] * len(ids)
-rt.prepare(0, ids, dur, kd.sym(1, (cfg.inter, 3 * len(ids)), 1.7), 0.667)
+noise = kd.sym(1, (cfg.inter, 3 * len(ids)), 1.7)
+if args.batch > 1:
+    rt.prepare_batch(0, [(ids, dur, noise)] * args.batch, 0.667)
+else:
+    rt.prepare(0, ids, dur, noise, 0.667)
 for _ in range(3):
     rt.launch(0); rt.collect(0)
 g = []
@@ -30,7 +35,7 @@ for _ in range(10):
     rt.launch(0); rt.collect(0); g.append(rt.last_gpu_ms(0))
 st = rt.profile(0, args.iters)
 tot = sum(s["avg_us"] for s in st)
-print(f"# {args.quality} {args.precision} factor={args.factor}: graph gpu_ms={sum(g)/len(g):.4f}  eager sum={tot:.1f} us  launches={len(st)}")
+print(f"# {args.quality} {args.precision} factor={args.factor} batch={args.batch}: graph gpu_ms={sum(g)/len(g):.4f}  eager sum={tot:.1f} us  launches={len(st)}")
 print(f"{'launch':44s} {'us':>9s} {'GFLOP':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}")
 for s in st:
     tf = s["flops"] / (s["avg_us"] * 1e-6) / 1e12 if s["avg_us"] > 0 else 0
