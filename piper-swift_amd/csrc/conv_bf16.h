@@ -56,5 +56,8 @@ bool conv_bf16_eligible(int Cout, int Cin, int K, int dil, int padL, int padR);
 bool convt_bf16_eligible(int Cin, int Cout, int K, int stride, int padL, int padR, int dil, int out_pad);
 
 int launch_conv_bf16(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args& a);
+// up to kBf16Multi independent convs of the same shape class (N, Cin, Cout, Lout, conv vs convT) in one launch
+constexpr int kBf16Multi = 3;
+int launch_conv_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args* convs, int count);
 
 }  // namespace ph

@@ -13,6 +13,8 @@
 //      fragment (16 B per lane, contiguous per wave) from L2 through an 8-deep register ring and the activation fragment
 //      (ds_read_b128, conflict-free: 32 consecutive positions of one channel block) from the window, double-buffered;
 //   3. epilogue: bias, fp32 residual, MRF mean, fp32 store and/or the C8 bf16 image of LeakyReLU(result) for the next conv.
+#include <algorithm>
+
 #include "conv_bf16.h"
 
 namespace ph {
@@ -84,9 +86,14 @@ __global__ __launch_bounds__(kBT) void pack_act_c8_kernel(const float* __restric
 
 // ---------------------------------------------------------------- the conv
 // WM waves along rows × (4/WM) along columns; each wave MTW × NTW tiles of 32×32.
+struct ConvBf16Multi {
+  ConvBf16Args c[kBf16Multi];
+};
+
 template <int MTW, int NTW, int WM>
-__global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
+__global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Multi multi, int batch) {
   extern __shared__ __attribute__((aligned(16))) uint4 win[];  // [Cin/8][W] positions of 8 channels + 1 dump slot
+  const ConvBf16Args& p = multi.c[blockIdx.z / batch];  // wave-uniform: which of the launch's convs this block works on
   constexpr int WN = 4 / WM;
   constexpr int NBC = WN * NTW * 32;  // columns per block
   const int lane = threadIdx.x & 63;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
   const bool ct = p.ct_stride > 0;
   const int taps = ct ? p.K / p.ct_stride : p.K;
   const int C16 = p.Cin >> 4, CB = p.Cin >> 3;
-  const int n = blockIdx.z;
+  const int n = blockIdx.z % batch;
   const int nb0 = blockIdx.x * NBC;                              // first column of the block
   const int mt0 = (blockIdx.y * WM + wm) * MTW;                  // first row tile of this wave
   // window: input positions [nb0 + off_min, nb0 + NBC + off_max)
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Args p) {
 }
 
 template <int MTW, int NTW, int WM>
-void launch_inst(hipStream_t s, const ConvBf16Args& a, dim3 grid, size_t lds) {
-  hipLaunchKernelGGL((conv_bf16_kernel<MTW, NTW, WM>), grid, dim3(kBT), lds, s, a);
+void launch_inst(hipStream_t s, const ConvBf16Multi& a, int batch, dim3 grid, size_t lds) {
+  hipLaunchKernelGGL((conv_bf16_kernel<MTW, NTW, WM>), grid, dim3(kBT), lds, s, a, batch);
 }
 
 template <int MTW, int NTW, int WM>
@@ -293,11 +300,11 @@ void raise_lds() {
   }
 }
 
-int launch_cfg(hipStream_t s, const ConvBf16Args& a, int MTW, int NTW, int WM, dim3 grid, size_t lds) {
+int launch_cfg(hipStream_t s, const ConvBf16Multi& a, int batch, int MTW, int NTW, int WM, dim3 grid, size_t lds) {
 #define PH_BF16_CASE(M, NT_, W_)                                 \
   if (MTW == M && NTW == NT_ && WM == W_) {                      \
     if (lds > 64 * 1024) raise_lds<M, NT_, W_>();                \
-    launch_inst<M, NT_, W_>(s, a, grid, lds);                    \
+    launch_inst<M, NT_, W_>(s, a, batch, grid, lds);             \
   } else
   PH_BF16_CASE(1, 1, 1) PH_BF16_CASE(1, 2, 1) PH_BF16_CASE(1, 4, 1)
   PH_BF16_CASE(1, 1, 2) PH_BF16_CASE(1, 2, 2) PH_BF16_CASE(1, 4, 2)
@@ -348,40 +355,50 @@ bool convt_bf16_eligible(int Cin, int Cout, int K, int stride, int padL, int pad
   return K % stride == 0 && padL == padR && K - stride == 2 * padL;
 }
 
-int launch_conv_bf16(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args& a) {
+int launch_conv_bf16(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args& a) { return launch_conv_bf16_multi(ctx, s, &a, 1); }
+
+int launch_conv_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args* convs, int count) {
+  if (count < 1 || count > kBf16Multi) PH_FAIL(PIPER_HIP_ERR_ARG, "conv_bf16: %d convs in one launch (1..%d)", count, kBf16Multi);
+  const ConvBf16Args& a = convs[0];
   if (a.N <= 0 || a.Lout <= 0) return PIPER_HIP_OK;
   const bool ct = a.ct_stride > 0;
   const int rows = ct ? a.Cout * a.ct_stride : a.Cout;
   const int MT = (rows + 31) / 32;
-  const int taps = ct ? a.K / a.ct_stride : a.K;
-  const int reach = ct ? (a.ct_stride - 1 + a.ct_pad) / a.ct_stride + taps - 1 : (a.K - 1) * a.dil;
+  auto reach_of = [&](const ConvBf16Args& b) {
+    const int taps = ct ? b.K / b.ct_stride : b.K;
+    return ct ? (b.ct_stride - 1 + b.ct_pad) / b.ct_stride + taps - 1 : (b.K - 1) * b.dil;
+  };
+  int reach = reach_of(a);
+  for (int i = 1; i < count; i++) {
+    const ConvBf16Args& b = convs[i];
+    if (b.N != a.N || b.Cin != a.Cin || b.Cout != a.Cout || b.Lout != a.Lout || b.ct_stride != a.ct_stride || b.x_row != a.x_row)
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv_bf16: convs of one launch must share N, Cin, Cout, Lout, row length and kind");
+    reach = std::max(reach, reach_of(b));
+  }
   // waves along rows: as many of the 4 as the row-tile count allows (ConvTranspose: a wave's tiles stay in one phase)
   const int per_phase = ct ? a.Cout / 32 : MT;
-  const int WM = (per_phase % 4 == 0) ? 4 : (per_phase % 2 == 0) ? 2 : 1;
-  const int WN = 4 / WM;
+  int WM = (per_phase % 4 == 0) ? 4 : (per_phase % 2 == 0) ? 2 : 1;
+  int WN = 4 / WM;
   int MTW = (per_phase % (2 * WM) == 0) ? 2 : 1;
   int NTW = 4;
-  auto blocks = [&](int mtw, int ntw) { return ceil_div(MT, WM * mtw) * ceil_div(a.Lout, WN * ntw * 32) * a.N; };
-  auto lds_bytes = [&](int ntw) { return (size_t)(a.Cin / 8) * (WN * ntw * 32 + reach) * 16 + 16; };
+  auto blocks = [&](int mtw, int ntw) { return ceil_div(MT, WM * mtw) * ceil_div(a.Lout, WN * ntw * 32) * a.N * count; };
+  auto lds_bytes = [&](int wn, int ntw) { return (size_t)(a.Cin / 8) * (wn * ntw * 32 + reach) * 16 + 16; };
   const int64_t want = 2 * (int64_t)ctx->num_cus;  // keep every CU busy before growing the per-wave tile
-  while (NTW > 1 && (blocks(MTW, NTW) < want || lds_bytes(NTW) > 160 * 1024)) NTW >>= 1;
+  while (NTW > 1 && (blocks(MTW, NTW) < want || lds_bytes(WN, NTW) > 160 * 1024)) NTW >>= 1;
   if (MTW == 2 && blocks(MTW, NTW) < want) MTW = 1;
   if (const char* force = getenv("PIPER_HIP_BF16_CFG")) {  // tuning hook: "MTW,NTW,WM" (ignored when it does not divide the problem)
     int m = 0, nt = 0, wmf = 0;
     if (sscanf(force, "%d,%d,%d", &m, &nt, &wmf) == 3 && (wmf == 1 || wmf == 2 || wmf == 4) && per_phase % (wmf * m) == 0 &&
-        (m == 1 || (m == 2 && wmf > 1)) && (nt == 1 || nt == 2 || nt == 4)) {
-      const int wn = 4 / wmf;
-      const size_t fl = (size_t)(a.Cin / 8) * (wn * nt * 32 + reach) * 16 + 16;
-      if (fl <= 160 * 1024) {
-        const dim3 g((unsigned)ceil_div(a.Lout, wn * nt * 32), (unsigned)ceil_div(MT, wmf * m), (unsigned)a.N);
-        return launch_cfg(s, a, m, nt, wmf, g, fl);
-      }
+        (m == 1 || (m == 2 && wmf > 1)) && (nt == 1 || nt == 2 || nt == 4) && lds_bytes(4 / wmf, nt) <= 160 * 1024) {
+      MTW = m; NTW = nt; WM = wmf; WN = 4 / wmf;
     }
   }
-  const size_t lds = lds_bytes(NTW);
+  const size_t lds = lds_bytes(WN, NTW);
   if (lds > 160 * 1024) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_bf16: window of %zu bytes does not fit LDS (Cin=%d reach=%d)", lds, a.Cin, reach);
-  const dim3 grid((unsigned)ceil_div(a.Lout, WN * NTW * 32), (unsigned)ceil_div(MT, WM * MTW), (unsigned)a.N);
-  return launch_cfg(s, a, MTW, NTW, WM, grid, lds);
+  const dim3 grid((unsigned)ceil_div(a.Lout, WN * NTW * 32), (unsigned)ceil_div(MT, WM * MTW), (unsigned)(a.N * count));
+  ConvBf16Multi multi;
+  for (int i = 0; i < kBf16Multi; i++) multi.c[i] = convs[i < count ? i : 0];
+  return launch_cfg(s, multi, a.N, MTW, NTW, WM, grid, lds);
 }
 
 }  // namespace ph

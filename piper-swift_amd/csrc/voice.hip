@@ -440,6 +440,30 @@ void add_conv_bf16(piper_hip_voice* v, Slot& s, const std::string& name, const p
   s.steps.push_back(std::move(st));
 }
 
+// several same-shape bf16 convs (the stage's ResBlocks) as one launch
+void add_conv_bf16_multi(piper_hip_voice* v, Slot& s, const std::string& name, const piper_hip_voice::ConvWB* const* ws,
+                         const ConvBf16Args* args, int count, double flops) {
+  struct Pack { ConvBf16Args a[kBf16Multi]; } pk;
+  double bytes = 0;
+  for (int i = 0; i < count; i++) {
+    ConvBf16Args a = args[i];
+    const auto& w = *ws[i];
+    a.w = w.w; a.bias = w.bias; a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K;
+    pk.a[i] = a;
+    const double cols = (double)a.N * a.Lout;
+    bytes += 2.0 * (w.Cin * cols + (double)w.Cout * w.Cin * w.K) + (a.act ? 2.0 : 0.0) * w.Cout * cols +
+             ((a.y ? 4.0 : 0.0) + (a.res ? 4.0 : 0.0) + (a.mrf_a ? 8.0 : 0.0)) * w.Cout * cols;
+  }
+  piper_hip_ctx* ctx = v->ctx;
+  Step st;
+  st.name = name;
+  st.run = [ctx, pk, count](hipStream_t q) { return launch_conv_bf16_multi(ctx, q, pk.a, count); };
+  st.flops = flops; st.bytes = bytes;
+  st.lane = 0;
+  st.tag = "conv_bf16";
+  s.steps.push_back(std::move(st));
+}
+
 // HiFi-GAN generator with bf16 contraction operands. Same graph as the fp32 generator below;
 // what changes is the data each conv READS: the C8 bf16 image of LeakyReLU(x) written by its producer's epilogue
 // (conv_bf16.h). The residual stream, the bias adds and the MRF mean stay fp32, so rounding enters only through the
@@ -450,7 +474,11 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
   const size_t B = (size_t)NB;
   hipStream_t zs = s.stream;
   static const bool no_par = getenv("PIPER_HIP_BF16_SERIAL_RB") != nullptr;
-  s.parallel = !no_par && c.resblock_type == 1;  // 18 convs per stage (high) gain 10 %; the 6 of ResBlock2 (medium) do not
+  static const bool no_merge = getenv("PIPER_HIP_NO_MERGED_RB") != nullptr;
+  // short utterances / small batches: the three ResBlocks advance in one launch; otherwise one launch per conv, as parallel
+  // graph branches for the 18-conv ResBlock1 stages (+10 %; the 6-conv ResBlock2 stages do not gain)
+  const bool merged = !no_merge && c.n_rb == 3 && (int64_t)NB * F <= 1536;
+  s.parallel = !merged && !no_par && c.resblock_type == 1;
   auto image = [&](int C, int L) -> uint16_t* {  // zeroed once per build: kernels write the interior only
     const size_t bytes = (size_t)c8_elems(NB, C, L) * 2;
     void* p = ar.raw(bytes);
@@ -504,6 +532,55 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
       a.N = NB; a.Lout = L; a.x_row = (int)c8_row_len(L); a.act_row = row; a.y_len = Lo;
       a.ct_stride = S.stride; a.ct_pad = S.pad;
       add_conv_bf16(v, s, p + "lrelu_convT", v->up_b[u], a, NB * 2.0 * S.Cin * S.Cout * (double)S.K * L);
+    }
+    if (merged) {
+      // conv i of rb0, rb1, rb2 have the same shape and no dependence on each other: one launch advances all three. Only the
+      // very last conv of rb2 runs alone, after the others, because its epilogue folds the MRF mean over r0, r1.
+      const float* src[3] = {up, up, up};
+      const uint16_t* src_act[3] = {a_up, a_up, a_up};
+      for (int di = 0; di < c.rb_n_dil; di++) {
+        const bool lastd = di + 1 == c.rb_n_dil;
+        const std::string nm = p + "rb012.c" + std::to_string(di);
+        ConvBf16Args aa[3], bb[3];
+        const piper_hip_voice::ConvWB *wa[3], *wb[3];
+        double fl[3];
+        for (int j = 0; j < 3; j++) {
+          const int K = c.rb_kernels[j], dl = c.rb_dilations[j][di];
+          fl[j] = NB * conv_flops(S.Cout, S.Cout, K, Lo);
+          auto base = [&](const uint16_t* in, int d2) {
+            ConvBf16Args a;
+            a.x = in; a.N = NB; a.dil = d2; a.padL = (K * d2 - d2) / 2; a.Lout = Lo; a.x_row = row; a.act_row = row; a.y_len = Lo;
+            a.act_alpha = 0.1f;
+            return a;
+          };
+          float* dst = lastd ? (j == 2 ? m : r[j]) : tmp[j][di & 1];
+          uint16_t* dst_act = lastd ? (j == 2 ? a_next : nullptr) : act[j][di & 1];
+          ConvBf16Args fin = base(c.resblock_type == 1 ? mid[j] : src_act[j], c.resblock_type == 1 ? 1 : dl);
+          fin.res = src[j]; fin.y = dst; fin.act = dst_act;
+          if (lastd && j == 2) { fin.mrf_a = r[0]; fin.mrf_b = r[1]; }
+          bb[j] = fin;
+          wb[j] = c.resblock_type == 1 ? &v->rb_b[u][j][2 * di + 1] : &v->rb_b[u][j][di];
+          if (c.resblock_type == 1) {
+            aa[j] = base(src_act[j], dl);
+            aa[j].act = mid[j];
+            wa[j] = &v->rb_b[u][j][2 * di];
+          }
+          src[j] = dst;
+          src_act[j] = dst_act;
+        }
+        if (c.resblock_type == 1) add_conv_bf16_multi(v, s, nm + "a_lrelu_conv_x3", wa, aa, 3, fl[0] + fl[1] + fl[2]);
+        const std::string bn = c.resblock_type == 1 ? "b" : "";
+        if (!lastd) {
+          add_conv_bf16_multi(v, s, nm + bn + "_lrelu_conv_res_x3", wb, bb, 3, fl[0] + fl[1] + fl[2]);
+        } else {
+          add_conv_bf16_multi(v, s, nm + bn + "_lrelu_conv_res_x2", wb, bb, 2, fl[0] + fl[1]);
+          add_conv_bf16_multi(v, s, nm + bn + "_lrelu_conv_res_mrfmean", wb + 2, bb + 2, 1, fl[2]);
+        }
+      }
+      a_in = a_next;
+      mean = m;
+      L = Lo;
+      continue;
     }
     // The stage's three ResBlocks are independent chains of short, latency-bound launches that leave most CUs idle:
     // rb0 / rb1 run as side branches of the graph, rb2 on the main lane, joined before rb2's last conv (which folds the
