@@ -189,22 +189,25 @@ def main():
             peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
             achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0
             traffic = None
-            try:  # HBM bytes per launch of this kernel family from the committed PMC passes of the same command
+            try:  # HBM bytes per launch of these kernel families from the committed PMC passes of the same command
+                def per_launch(path, families):
+                    pj = json.load(open(os.path.join(ROOT, "profiles", path)))
+                    fam = [pj["traffic"][f] for f in families if f in pj["traffic"]]
+                    n = sum(f["launches"] for f in fam)
+                    return sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None
                 if args.factor == 8 and args.quality == "medium" and not bf16:
-                    pj = json.load(open(os.path.join(ROOT, "profiles", "r1b_rocprof_summary.json")))
-                    traffic = pj["traffic"]["conv_stream_kernel"]["hbm_mb_per_launch"] * 1e6
+                    traffic = per_launch("r1c_rocprof_summary.json", ("conv_stream_kernel", "conv_win_kernel"))
                 elif args.factor == 8 and args.quality == "high" and bf16:
-                    pj = json.load(open(os.path.join(ROOT, "profiles", "r1b_high_bf16_rocprof_summary.json")))
-                    traffic = pj["traffic"]["conv_bf16_kernel"]["hbm_mb_per_launch"] * 1e6
+                    traffic = per_launch("r1c_high_bf16_rocprof_summary.json", ("conv_bf16_kernel",))
             except Exception:
                 pass
             out["roofline"] = {
                 "kernel": ("conv_bf16_kernel (bf16-operand MFMA Conv1d/ConvTranspose1d of the generator, LDS-resident input window; all of its launches in one utterance)"
                            if bf16 else
-                           "conv_stream_kernel (fp32 MFMA implicit-GEMM Conv1d/ConvTranspose1d; all of its launches in one utterance)"),
+                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_stream_kernel for short rows + conv_win_kernel for the generator long rows; all of their launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r1b*_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "traffic_note": "HBM bytes per launch from profiles/r1c*_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; algorithmic bytes per launch "
                                 f"= {m_by / max(1, n_l) / 1e6:.2f} MB",
                 "timing": "HIP events around a graph replay of only these launches (30 replays)",
