@@ -304,3 +304,29 @@ def test_voice_loaded_from_onnx_file(backend, voices, tmp_path):
         assert_close(rt.synthesize(ids, dur, noise, 0.667), orc.synthesize(cfg, blob, ids, dur, noise, 0.667), WAVE_TOL, "onnx voice")
     finally:
         rt.close()
+
+
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_large_batch_takes_the_per_conv_schedules(quality, voices, backend):
+    """NB·F above the merge threshold (1536): fp32 runs one launch per ResBlock conv with the MRF mean fused into its
+    producer, bf16 additionally uses parallel graph branches for ResBlock1. Both must still match the oracle."""
+    cfg, blob = voices[quality]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        T, F, NB = 28, 84, 20
+        rng = np.random.RandomState(11)
+        utts = [(list(rng.randint(0, 130, size=T)), [3] * T, kd.sym(SD + 700 + b, (cfg.inter, F), 1.7320508)) for b in range(NB)]
+        refs = {b: orc.synthesize(cfg, blob, utts[b][0], utts[b][1], utts[b][2], 0.667) for b in (0, NB - 1)}
+        rt.prepare_batch(2, utts, 0.667)
+        rt.launch(2)
+        audio = rt.collect(2).reshape(NB, -1)
+        for b, ref in refs.items():
+            assert_close(audio[b], ref, WAVE_TOL, f"fp32 batch item {b}")
+        rt.set_precision("bf16")
+        rt.prepare_batch(2, utts, 0.667)
+        rt.launch(2)
+        audio = rt.collect(2).reshape(NB, -1)
+        for b, ref in refs.items():
+            assert snr_db(audio[b], ref) >= BF16_MIN_SNR_DB, (b, snr_db(audio[b], ref))
+    finally:
+        rt.close()
