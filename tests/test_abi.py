@@ -101,3 +101,16 @@ def test_fails_loudly_without_gpu():
     p = C.c_void_p()
     assert lib.piper_hip_alloc(None, 16, C.byref(p)) == -7
     assert lib.piper_hip_unary_f32(None, 0, None, 4, 0.0, C.byref(p), None) == -7
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: both headers compile as C99 and a plain-C host (examples/synth_demo.c) links against it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for h in ("piper_hip.h", "piper_hip_voice_layout.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", h)])
+    lib = os.path.join(root, "piper-swift_amd", "lib")
+    exe = tmp_path / "synth_demo"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "synth_demo.c"),
+                           "-L" + lib, "-lpiper_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    assert exe.exists()

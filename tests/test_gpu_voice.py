@@ -330,3 +330,23 @@ def test_large_batch_takes_the_per_conv_schedules(quality, voices, backend):
             assert snr_db(audio[b], ref) >= BF16_MIN_SNR_DB, (b, snr_db(audio[b], ref))
     finally:
         rt.close()
+
+
+def test_c_host_program_end_to_end(rt_medium, tmp_path):
+    """examples/synth_demo.c (plain C over the C-ABI, no Python) writes the same 16-bit samples as the ctypes path."""
+    import os
+    import subprocess
+    import wave
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "piper-swift_amd", "lib")
+    exe, wav = tmp_path / "synth_demo", tmp_path / "c_host.wav"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "synth_demo.c"),
+                           "-L" + lib, "-lpiper_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    out = subprocess.run([str(exe), str(wav), "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ids, dur = kd.FIXTURE_IDS * 2, [3] * 28
+    ref = ph.pcm16(rt_medium.synthesize(ids, dur, None, 0.667))
+    with wave.open(str(wav), "rb") as w:
+        assert w.getframerate() == 22050 and w.getnframes() == ref.size
+        got = np.frombuffer(w.readframes(ref.size), "<i2")
+    assert np.array_equal(got, ref)
