@@ -326,6 +326,26 @@ def main():
             out["batch32"] = {"utterances": len(plan), "audio_sec": round(b_audio, 2), "ms_per_batch": round(dt * 1e3, 3),
                               "utterances_per_sec": round(len(plan) / dt, 1), "audio_sec_per_wall_sec": round(b_audio / dt, 1),
                               "slots": nslot, "note": "32 mixed-length utterances (factors 1..16), LPT-sharded over ranks, graphs cached per shape"}
+            # the same shard bucketed by shape: utterances of equal (T, F) go through ONE schedule (prepare_batch), one slot per shape
+            groups = sorted(by_factor.items())
+            if len(groups) <= 16 and any(len(ix) > 1 for _, ix in groups):
+                for sl, (f, idxs) in enumerate(groups):
+                    rt.prepare_batch(sl, [utterance(f, 3000 + 17 * f + k, cfg.inter) for k in range(len(idxs))], 0.667)
+
+                def run_bucketed():
+                    for sl in range(len(groups)):
+                        rt.launch(sl)
+                    for sl in range(len(groups)):
+                        rt.collect(sl, want_audio=False)
+                run_bucketed()
+                a = time.perf_counter()
+                for _ in range(reps):
+                    run_bucketed()
+                dt2 = (time.perf_counter() - a) / reps
+                out["batch32"]["bucketed_by_shape"] = {"launches": len(groups), "ms_per_batch": round(dt2 * 1e3, 3),
+                                                       "utterances_per_sec": round(len(plan) / dt2, 1),
+                                                       "audio_sec_per_wall_sec": round(b_audio / dt2, 1)}
+                rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
         # ---- CPU baseline: the oracle (C restatement, OpenMP) on the same workload, bounded sample
         if not args.no_cpu_baseline and world == 1:
             import oracle as orc
