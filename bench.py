@@ -346,6 +346,35 @@ def main():
                                                        "utterances_per_sec": round(len(plan) / dt2, 1),
                                                        "audio_sec_per_wall_sec": round(b_audio / dt2, 1)}
                 rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
+        # ---- streaming (synthesizeStream): time to the first audio chunk vs the whole utterance, long-form input
+        if not args.no_scale_bench:
+            sf, chunk = 64, 64
+            si, sd, sn = utterance(sf, 4242, cfg.inter)
+            for _ in range(2):  # builds and caches the schedules / graphs of the three window widths
+                for _c in rt.synthesize_stream(si, sd, sn, 0.667, chunkFrames=chunk, slot=13):
+                    pass
+            firsts, totals = [], []
+            for _ in range(10):
+                a = time.perf_counter()
+                g = rt.synthesize_stream(si, sd, sn, 0.667, chunkFrames=chunk, slot=13)
+                next(g)
+                firsts.append(time.perf_counter() - a)
+                for _c in g:
+                    pass
+                totals.append(time.perf_counter() - a)
+            rt.prepare(13, si, sd, sn, 0.667)
+            whole = []
+            for _ in range(10):
+                a = time.perf_counter()
+                rt.launch(13)
+                rt.collect(13)
+                whole.append(time.perf_counter() - a)
+            out["streaming"] = {"factor": sf, "frames": int(sum(sd)), "chunk_frames": chunk,
+                                "chunk_audio_sec": round(chunk * hop / sr, 3),
+                                "first_audio_ms": round(float(np.mean(firsts)) * 1e3, 3),
+                                "all_chunks_ms": round(float(np.mean(totals)) * 1e3, 3),
+                                "whole_utterance_ms": round(float(np.mean(whole)) * 1e3, 3),
+                                "note": "encoder + flow once, generator per window of chunk + receptive-field halo"}
         # ---- CPU baseline: the oracle (C restatement, OpenMP) on the same workload, bounded sample
         if not args.no_cpu_baseline and world == 1:
             import oracle as orc

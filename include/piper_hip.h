@@ -356,6 +356,16 @@ int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot);
 int piper_hip_voice_launch(piper_hip_voice* v, int slot);
 /* Wait for the slot and copy the waveform(s) [batch · num_samples] to host (NULL = just wait). */
 int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples);
+/* Streaming ⇔ PiperMetalRuntime.synthesizeStream (PiperMetalRuntime.swift:82-115) — which "today chunks the final
+ * waveform". Here the text encoder and the flow run once (stream_begin) and the HiFi-GAN generator decodes the latent
+ * window by window: each stream_next decodes `chunk_frames` frames plus the generator's receptive field on both sides
+ * (piper_hip_voice_receptive_field frames; clamped at the utterance's ends) and returns chunk_frames · hop samples, so the
+ * first audio is available after encoder + flow + one window instead of the whole utterance. The samples equal
+ * synthesize()'s up to fp32 summation order (tile splits depend on the window length). Batch 1.
+ * stream_begin returns the number of chunks (≥ 1) or a negative status; stream_next sets *n_samples = 0 at the end. */
+int piper_hip_voice_receptive_field(const piper_hip_voice* v);
+int piper_hip_voice_stream_begin(piper_hip_voice* v, const piper_hip_utterance* u, int slot, int chunk_frames);
+int piper_hip_voice_stream_next(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples, int64_t* n_samples);
 /* prepare + launch + collect: PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80). */
 int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u, float* host_audio,
                                int64_t max_samples, int64_t* n_samples);

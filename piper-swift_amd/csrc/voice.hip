@@ -159,6 +159,12 @@ struct Slot {
   hipGraphExec_t exec = nullptr;
   bool timed = false;
   bool parallel = false;  // capture FORK/JOIN lanes as parallel graph branches (set by the schedule builder)
+  float* zin = nullptr;   // generator-only schedule (streaming): the latent window [inter, F] it decodes
+  const float* z_out = nullptr;  // full schedule: where the flow leaves z
+  // streaming state of a full-schedule slot (piper_hip_voice_stream_*)
+  hipGraph_t front_graph = nullptr;
+  hipGraphExec_t front_exec = nullptr;  // encoder + flow only
+  int st_chunk = 0, st_next = -1, st_halo = 0;
   int cur_lane = 0;  // lane given to steps added by add_conv
   // host staging (pinned so the H2D copies are truly async)
   int64_t* h_ids = nullptr;
@@ -207,6 +213,7 @@ struct piper_hip_voice {
   std::vector<std::vector<std::vector<ConvWB>>> rb_b;   // [stage][rb][conv]
   std::vector<void*> owned;
   Slot slots[kMaxSlots];
+  std::map<int, std::unique_ptr<Slot>> gen_slots;  // streaming: generator-only schedules by window width (frames)
   int hop = 1;
 };
 
@@ -362,6 +369,9 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
 void slot_release(piper_hip_voice* v, Slot& s, bool all) {
   if (s.exec) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
   if (s.graph) { (void)hipGraphDestroy(s.graph); s.graph = nullptr; }
+  if (s.front_exec) { (void)hipGraphExecDestroy(s.front_exec); s.front_exec = nullptr; }
+  if (s.front_graph) { (void)hipGraphDestroy(s.front_graph); s.front_graph = nullptr; }
+  s.st_next = -1; s.zin = nullptr; s.z_out = nullptr;
   for (void* p : s.owned) (void)v->ctx->pool.release(p);
   s.owned.clear();
   s.steps.clear();
@@ -781,7 +791,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   return PIPER_HIP_OK;
 }
 
-int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
+int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_only = false) {
   const piper_hip_voice_config& c = v->cfg;
   piper_hip_ctx* ctx = v->ctx;
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
@@ -793,6 +803,20 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   s.T = T; s.F = F; s.NB = NB;
   s.parallel = parallel_rb;
   const size_t B = (size_t)NB;
+  auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L) {
+    ConvArgs a;
+    a.x = in; a.y = out; a.N = NB; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
+    a.y_len = L;
+    return a;
+  };
+  const float* z = nullptr;
+  float* dec0 = nullptr;
+  if (gen_only) {  // streaming: only the generator, over a window of the latent that the caller copies into zin
+    s.zin = ar.f32(B * (size_t)I * F);
+    dec0 = ar.f32(B * (size_t)c.up_initial * F);
+    if (ar.rc) return ar.rc;
+    z = s.zin;
+  } else {
   s.ids = (int64_t*)ar.raw(B * T * sizeof(int64_t));
   s.frame2id = (int32_t*)ar.raw(B * F * sizeof(int32_t));
   s.noise = ar.f32(B * I * F);
@@ -811,7 +835,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
   float* h = ar.f32(B * (size_t)H * F);
   float* acts = ar.f32(B * (size_t)H * F);
   float* skip = ar.f32(B * (size_t)H * F);
-  float* dec0 = ar.f32(B * (size_t)c.up_initial * F);
+  dec0 = ar.f32(B * (size_t)c.up_initial * F);
   if (ar.rc) return ar.rc;
   {
     Step st;
@@ -827,12 +851,6 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
     };
     s.steps.push_back(st);
   }
-  auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L) {
-    ConvArgs a;
-    a.x = in; a.y = out; a.N = NB; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
-    a.y_len = L;
-    return a;
-  };
   const int kf = c.ffn_kernel;
   for (int l = 0; l < c.n_layers; l++) {
     const auto& L = v->enc[l];
@@ -934,7 +952,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
       add_conv(v, s, p + "post_sub", C.post, a, F);
     }
   }
-  const float* z = zp;
+  z = zp;
   if (flipped) {  // odd number of couplings: materialise the last Flip once
     Step st;
     st.name = "flow.final_flip";
@@ -946,6 +964,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB) {
     s.steps.push_back(st);
     z = zflip;
   }
+  s.z_out = z;
+  }  // !gen_only
   s.taps["z"] = {z, B * I * F};
   if (v->precision == PIPER_HIP_PRECISION_BF16) return build_generator_bf16(v, s, ar, z, dec0, F, NB);
   // ---------------- HiFi-GAN generator
@@ -1299,6 +1319,8 @@ PH_EXPORT int piper_hip_voice_set_precision(piper_hip_voice* v, int precision) {
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_set_precision: packing failed: %s", hipGetErrorString(e));
   }
   for (auto& s : v->slots) slot_release(v, s, false);  // schedules are rebuilt by the next prepare
+  for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
+  v->gen_slots.clear();
   v->precision = precision;
   return PIPER_HIP_OK;
 }
@@ -1310,6 +1332,7 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
   (void)hipSetDevice(v->ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& s : v->slots) slot_release(v, s, true);
+  for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
   for (void* p : v->owned) (void)v->ctx->pool.release(p);
   delete v;
 }
@@ -1432,6 +1455,131 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     PH_HIP(hipMemcpyAsync(host_audio, s.audio, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
   }
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  return PIPER_HIP_OK;
+}
+
+// ---- streaming: encoder + flow once, then the generator window by window --------------------------------------------
+namespace {
+
+// Frames of latent the generator needs on each side of an output frame (its receptive field, walked from the waveform back
+// to z): conv_post ±3 samples; per stage the widest ResBlock reach, then the ConvTranspose; conv_pre ±3 frames.
+int generator_halo_frames(const piper_hip_voice_config& c) {
+  int64_t r = 3;
+  for (int u = c.n_ups - 1; u >= 0; u--) {
+    int64_t rb = 0;
+    for (int j = 0; j < c.n_rb; j++) {
+      int64_t reach = 0;
+      for (int di = 0; di < c.rb_n_dil; di++) {
+        const int64_t k = c.rb_kernels[j], d = c.rb_dilations[j][di];
+        reach += (k * d - d) / 2 + (c.resblock_type == 1 ? (k - 1) / 2 : 0);
+      }
+      rb = std::max(rb, reach);
+    }
+    r += rb;
+    r = (r + c.up_kernels[u]) / c.up_rates[u] + 1;
+  }
+  return (int)(r + 3);
+}
+
+// graph of the steps selected by `pick` (eager pass first: validates launches and sets kernel attributes)
+int capture_steps(Slot& s, const std::vector<int>& pick, hipGraph_t* g, hipGraphExec_t* ge) {
+  for (int i : pick) {
+    int rc = s.steps[i].run(s.stream);
+    if (rc) return rc;
+  }
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
+  int rc = PIPER_HIP_OK;
+  for (int i : pick)
+    if ((rc = s.steps[i].run(s.stream))) break;
+  hipError_t ce = hipStreamEndCapture(s.stream, g);
+  if (rc || ce != hipSuccess) {
+    if (*g) { (void)hipGraphDestroy(*g); *g = nullptr; }
+    if (rc) return rc;
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "stream: graph capture failed: %s", hipGetErrorString(ce));
+  }
+  ce = hipGraphInstantiate(ge, *g, nullptr, nullptr, 0);
+  if (ce != hipSuccess) {
+    (void)hipGraphDestroy(*g); *g = nullptr;
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "stream: graph instantiate failed: %s", hipGetErrorString(ce));
+  }
+  return PIPER_HIP_OK;
+}
+
+// generator-only schedule for a window of `Fc` frames (cached per width)
+int generator_slot(piper_hip_voice* v, int Fc, Slot** out) {
+  auto it = v->gen_slots.find(Fc);
+  if (it != v->gen_slots.end() && it->second->exec) { *out = it->second.get(); return PIPER_HIP_OK; }
+  if (v->gen_slots.size() >= 6) {  // first / interior / last window widths of a couple of chunk sizes; beyond that start over
+    PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);
+    for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
+    v->gen_slots.clear();
+  }
+  std::unique_ptr<Slot> gs(new Slot());
+  int rc = slot_init(v, *gs);
+  if (rc) return rc;
+  if ((rc = build_schedule(v, *gs, 0, Fc, 1, true))) { slot_release(v, *gs, true); return rc; }
+  std::vector<int> all;
+  for (int i = 0; i < (int)gs->steps.size(); i++)
+    if (gs->steps[i].kind == Step::LAUNCH) all.push_back(i);
+  if ((rc = capture_steps(*gs, all, &gs->graph, &gs->exec))) { slot_release(v, *gs, true); return rc; }
+  *out = gs.get();
+  v->gen_slots[Fc] = std::move(gs);
+  return PIPER_HIP_OK;
+}
+
+}  // namespace
+
+PH_EXPORT int piper_hip_voice_receptive_field(const piper_hip_voice* v) { return v ? generator_halo_frames(v->cfg) : -1; }
+
+PH_EXPORT int piper_hip_voice_stream_begin(piper_hip_voice* v, const piper_hip_utterance* u, int slot, int chunk_frames) {
+  if (chunk_frames < 1) PH_FAIL(PIPER_HIP_ERR_ARG, "stream_begin: chunk_frames must be >= 1");
+  int rc = piper_hip_voice_prepare(v, u, slot);
+  if (rc < 0) return rc;
+  Slot& s = v->slots[slot];
+  if (!s.front_exec) {  // encoder + flow as their own graph (everything before the generator's first launch)
+    std::vector<int> front;
+    for (int i = 0; i < (int)s.steps.size(); i++) {
+      if (s.steps[i].name.compare(0, 4, "dec.") == 0) break;
+      if (s.steps[i].kind == Step::LAUNCH) front.push_back(i);
+    }
+    if ((rc = capture_steps(s, front, &s.front_graph, &s.front_exec))) return rc;
+  }
+  PH_HIP(hipGraphLaunch(s.front_exec, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipEventRecord(s.ev1, s.stream), PIPER_HIP_ERR_LAUNCH);  // z is ready when ev1 fires
+  s.st_chunk = chunk_frames;
+  s.st_halo = generator_halo_frames(v->cfg);
+  s.st_next = 0;
+  return (int)ceil_div(s.F, chunk_frames);
+}
+
+PH_EXPORT int piper_hip_voice_stream_next(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples, int64_t* n_samples) {
+  if (!v || !n_samples) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (slot < 0 || slot >= kMaxSlots || v->slots[slot].st_next < 0) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no stream in progress", slot);
+  Slot& s = v->slots[slot];
+  *n_samples = 0;
+  if (s.st_next >= s.F) return PIPER_HIP_OK;  // end of stream
+  const int f0 = s.st_next, f1 = std::min(s.F, f0 + s.st_chunk);
+  // window = chunk + receptive field, clamped to the utterance: at the utterance's own ends the convs' zero padding is
+  // then the same zero padding the whole-utterance run sees, inside it the halo frames are recomputed and dropped
+  const int a = std::max(0, f0 - s.st_halo), b = std::min(s.F, f1 + s.st_halo);
+  const int Fc = b - a;
+  const int64_t want = (int64_t)(f1 - f0) * v->hop;
+  if (host_audio && max_samples < want) PH_FAIL(PIPER_HIP_ERR_SHAPE, "stream_next: buffer holds %lld < %lld samples", (long long)max_samples, (long long)want);
+  Slot* gs = nullptr;
+  int rc = generator_slot(v, Fc, &gs);
+  if (rc) return rc;
+  const int I = v->cfg.inter;
+  PH_HIP(hipStreamWaitEvent(gs->stream, s.ev1, 0), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpy2DAsync(gs->zin, (size_t)Fc * sizeof(float), s.z_out + a, (size_t)s.F * sizeof(float), (size_t)Fc * sizeof(float), (size_t)I,
+                          hipMemcpyDeviceToDevice, gs->stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipGraphLaunch(gs->exec, gs->stream), PIPER_HIP_ERR_LAUNCH);
+  if (host_audio)
+    PH_HIP(hipMemcpyAsync(host_audio, gs->audio + (int64_t)(f0 - a) * v->hop, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, gs->stream),
+           PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipStreamSynchronize(gs->stream), PIPER_HIP_ERR_LAUNCH);
+  *n_samples = want;
+  s.st_next = f1;
   return PIPER_HIP_OK;
 }
 

@@ -178,6 +178,9 @@ _PROTOS = {
     "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
     "piper_hip_pcm16_from_f32": (C.c_int, [c_f32p, C.c_size_t, C.POINTER(C.c_int16)]),
     "piper_hip_wav_write": (C.c_int, [C.c_char_p, c_f32p, C.c_size_t, C.c_int32]),
+    "piper_hip_voice_receptive_field": (C.c_int, [c_vp]),
+    "piper_hip_voice_stream_begin": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
+    "piper_hip_voice_stream_next": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
@@ -685,6 +688,20 @@ class HipRuntime:
         if rc < 0:
             _check(rc)
         return rc
+
+    def synthesize_stream(self, phonemeIDs, durations, noise=None, noiseScale=0.667, chunkFrames=64, slot=0):
+        """Generator of waveform chunks (PiperMetalRuntime.synthesizeStream): encoder + flow once, generator per window."""
+        u, keep = self._utt(phonemeIDs, durations, noise, noiseScale)
+        n_chunks = self.lib.piper_hip_voice_stream_begin(self.voice, C.byref(u), slot, int(chunkFrames))
+        if n_chunks < 0:
+            _check(n_chunks)
+        buf = np.empty(int(chunkFrames) * self.cfg.hop, np.float32)
+        got = C.c_int64()
+        while True:
+            _check(self.lib.piper_hip_voice_stream_next(self.voice, slot, buf.ctypes.data_as(c_f32p), buf.size, C.byref(got)))
+            if got.value == 0:
+                return
+            yield buf[:got.value].copy()
 
     def prepare_batch(self, slot, utterances, noiseScale=0.667):
         """utterances: list of (phonemeIDs, durations, noise-or-None), all with the same T and the same Σ durations."""

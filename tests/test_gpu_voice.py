@@ -1,4 +1,5 @@
 """GPU: whole-utterance path (piper_hip_voice_*) vs oracle, golden vectors and size-independent properties."""
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -350,3 +351,43 @@ def test_c_host_program_end_to_end(rt_medium, tmp_path):
         assert w.getframerate() == 22050 and w.getnframes() == ref.size
         got = np.frombuffer(w.readframes(ref.size), "<i2")
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("quality,factor,chunk", [("medium", 8, 64), ("medium", 8, 50), ("medium", 1, 64), ("high", 4, 32)])
+def test_streaming_generator_matches_whole_utterance(quality, factor, chunk, voices, backend):
+    """stream_begin / stream_next: encoder + flow once, generator window by window with the receptive field as halo.
+    Concatenated chunks must equal synthesize() up to fp32 summation order (tile splits depend on the window length)."""
+    cfg, blob = voices[quality]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        ids = kd.FIXTURE_IDS * factor
+        dur = [3] * len(ids)
+        F = sum(dur)
+        noise = kd.sym(SD + 800 + factor, (cfg.inter, F), 1.7320508)
+        whole = rt.synthesize(ids, dur, noise, 0.667)
+        chunks = list(rt.synthesize_stream(ids, dur, noise, 0.667, chunkFrames=chunk, slot=3))
+        assert len(chunks) == -(-F // chunk)
+        assert all(c.size == chunk * cfg.hop for c in chunks[:-1])
+        streamed = np.concatenate(chunks)
+        assert streamed.size == whole.size
+        assert_close(streamed, whole, 2e-5, f"streamed vs whole ({quality}, factor {factor}, chunk {chunk})")
+        halo = rt.lib.piper_hip_voice_receptive_field(rt.voice)
+        assert 8 <= halo <= 24
+        # a second stream on the same slot (cached graphs) gives the same samples
+        again = np.concatenate(list(rt.synthesize_stream(ids, dur, noise, 0.667, chunkFrames=chunk, slot=3)))
+        assert np.array_equal(again, streamed)
+        if quality == "medium" and factor == 8 and chunk == 64:
+            rt.set_precision("bf16")
+            whole_b = rt.synthesize(ids, dur, noise, 0.667)
+            streamed_b = np.concatenate(list(rt.synthesize_stream(ids, dur, noise, 0.667, chunkFrames=chunk, slot=3)))
+            assert snr_db(streamed_b, whole_b) >= 40.0, snr_db(streamed_b, whole_b)
+    finally:
+        rt.close()
+
+
+def test_streaming_errors(rt_medium):
+    ids, dur = kd.FIXTURE_IDS, [3] * 14
+    with pytest.raises(ph.ExecutionError):
+        list(rt_medium.synthesize_stream(ids, dur, None, 0.667, chunkFrames=0))
+    got = C.c_int64()
+    assert rt_medium.lib.piper_hip_voice_stream_next(rt_medium.voice, 9, None, 0, C.byref(got)) != 0  # no stream on slot 9
