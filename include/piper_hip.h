@@ -59,6 +59,11 @@ int piper_hip_device_count(void);
 /* MetalContext.init (Metal/MetalContext.swift:9-33) + MetalBackend.init (MetalBackend.swift:12-15). */
 int piper_hip_create(int device, piper_hip_ctx** out);
 void piper_hip_destroy(piper_hip_ctx* ctx);
+/* Device memory held by the context's pool (buffers + cached free blocks) and the part currently handed out. The pool
+ * recycles power-of-two blocks, so a host that sees many utterance shapes plateaus instead of growing; `memory_trim`
+ * returns the cached free blocks to the driver (the role ARC plays for MTLBuffer in the reference). */
+int piper_hip_memory_stats(piper_hip_ctx* ctx, size_t* reserved_bytes, size_t* live_bytes);
+int piper_hip_memory_trim(piper_hip_ctx* ctx);
 /* MetalBackend.allocateBuffer(length:) (MetalBackend.swift:34-39): at least 1 byte is allocated. */
 int piper_hip_alloc(piper_hip_ctx* ctx, size_t bytes, void** out);
 /* Buffer release (ARC drop in the reference; GraphExecutor.swift:216-225). Returns memory to the

@@ -239,3 +239,29 @@ PH_EXPORT int piper_hip_timer_end(piper_hip_ctx* ctx, piper_hip_stream s, double
   if (gpu_ms) *gpu_ms = ms;
   return PIPER_HIP_OK;
 }
+
+// ---- memory accounting for long-running hosts (serving: many utterance shapes over the life of a process)
+PH_EXPORT int piper_hip_memory_stats(piper_hip_ctx* ctx, size_t* reserved_bytes, size_t* live_bytes) {
+  PH_CHECK_CTX(ctx);
+  std::lock_guard<std::mutex> lk(ctx->pool.mu);
+  size_t live = 0;
+  for (auto& kv : ctx->pool.live) live += kv.second;
+  if (reserved_bytes) *reserved_bytes = ctx->pool.bytes_reserved;
+  if (live_bytes) *live_bytes = live;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_memory_trim(piper_hip_ctx* ctx) {
+  PH_CHECK_CTX(ctx);
+  PH_HIP(hipSetDevice(ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);  // cached blocks may still be referenced by queued work
+  ph::release_deferred(ctx);
+  std::lock_guard<std::mutex> lk(ctx->pool.mu);
+  for (auto& kv : ctx->pool.free_blocks) {
+    for (void* q : kv.second) (void)hipFree(q);
+    ctx->pool.bytes_reserved -= kv.first * kv.second.size();
+    kv.second.clear();
+  }
+  return PIPER_HIP_OK;
+}
+

@@ -181,6 +181,8 @@ _PROTOS = {
     "piper_hip_voice_receptive_field": (C.c_int, [c_vp]),
     "piper_hip_voice_stream_begin": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
     "piper_hip_voice_stream_next": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    "piper_hip_memory_stats": (C.c_int, [c_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "piper_hip_memory_trim": (C.c_int, [c_vp]),
     "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
@@ -305,6 +307,14 @@ class HipBackend:
         self.close()
 
     # -- buffers (MetalBackend.swift:34-39, 963-993)
+    def memory_stats(self):
+        r, l = C.c_size_t(), C.c_size_t()
+        _check(self.lib.piper_hip_memory_stats(self.ctx, C.byref(r), C.byref(l)))
+        return dict(reserved=r.value, live=l.value)
+
+    def memory_trim(self):
+        _check(self.lib.piper_hip_memory_trim(self.ctx))
+
     def allocateBuffer(self, length):
         p = c_vp()
         _check(self.lib.piper_hip_alloc(self.ctx, length, C.byref(p)))

@@ -391,3 +391,38 @@ def test_streaming_errors(rt_medium):
         list(rt_medium.synthesize_stream(ids, dur, None, 0.667, chunkFrames=0))
     got = C.c_int64()
     assert rt_medium.lib.piper_hip_voice_stream_next(rt_medium.voice, 9, None, 0, C.byref(got)) != 0  # no stream on slot 9
+
+
+def test_soak_many_shapes_memory_plateaus(backend, voices):
+    """A serving process sees many (T, F): schedules are rebuilt per shape, the pool recycles their buffers. Two passes over
+    the same 60 random shapes must not grow device memory in the second pass, results stay correct, trim gives memory back."""
+    cfg, blob = voices["medium"]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        rng = np.random.RandomState(5)
+        shapes = []
+        for _ in range(60):
+            T = int(rng.randint(3, 120))
+            dur = rng.randint(0, 6, size=T).astype(int).tolist()
+            if sum(dur) == 0:
+                dur[0] = 2
+            shapes.append((rng.randint(0, 130, size=T).tolist(), dur))
+        check = {7, 31, 59}
+
+        def one_pass(verify):
+            for i, (ids, dur) in enumerate(shapes):
+                audio = rt.synthesize(ids, dur, None, 0.667)
+                assert audio.size == sum(dur) * cfg.hop and np.all(np.isfinite(audio))
+                if verify and i in check:
+                    assert_close(audio, orc.synthesize(cfg, blob, ids, dur, None, 0.667), WAVE_TOL, f"soak item {i}")
+        one_pass(True)
+        first = backend.memory_stats()
+        one_pass(False)
+        second = backend.memory_stats()
+        assert second["reserved"] <= first["reserved"] * 1.05 + (1 << 20), (first, second)
+        backend.memory_trim()
+        trimmed = backend.memory_stats()
+        assert trimmed["reserved"] <= second["reserved"] and trimmed["reserved"] >= trimmed["live"]
+        assert np.all(np.isfinite(rt.synthesize(*shapes[0], None, 0.667)))  # still works after the trim
+    finally:
+        rt.close()
