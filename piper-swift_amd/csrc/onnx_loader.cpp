@@ -14,7 +14,9 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <memory>
 
@@ -65,9 +67,12 @@ struct Tensor {
   const uint8_t* raw = nullptr;  size_t raw_len = 0;    // field 9
   const uint8_t* fdat = nullptr; size_t fdat_len = 0;   // field 4, packed
   std::vector<float> floats_unpacked;                    // field 4, unpacked encoding (rare)
-  int64_t count() const {
+  int64_t count() const {  // -1 for negative dims or a product that does not fit (hostile / corrupt files)
     int64_t n = 1;
-    for (int64_t d : dims) n *= d;
+    for (int64_t d : dims) {
+      if (d < 0 || (d != 0 && n > INT64_MAX / d)) return -1;
+      n *= d;
+    }
     return n;
   }
 };

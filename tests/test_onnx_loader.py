@@ -144,3 +144,28 @@ def test_wav_writer_matches_reference_conversion(tmp_path):
     assert p.stat().st_size == 44 + 2 * x.size
     with pytest.raises(ph.ExecutionError):
         ph.wav_write(tmp_path / "no_such_dir" / "x.wav", x)
+
+
+def test_onnx_reader_under_sanitizers(tmp_path):
+    """tools/fuzz/fuzz_onnx.cpp: the reader compiled with g++ -fsanitize=address,undefined (CPU build; GPU sanitizers are
+    not available on the pool) over every prefix and 1500 random byte mutations of a tiny Piper-shaped model."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++") or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs g++ and the HIP headers")
+    cfg = ph.voice_config("medium")
+    cfg.hidden, cfg.n_heads, cfg.n_layers, cfg.ffn, cfg.inter = 32, 2, 1, 64, 64
+    cfg.n_flows, cfg.wn_layers, cfg.up_initial, cfg.n_vocab = 1, 1, 64, 16
+    blob = ph.synthetic_blob(cfg, 7)
+    seed = tmp_path / "seed.onnx"
+    seed.write_bytes(ow.piper_voice_onnx(cfg, blob, layout_dicts(cfg), weight_norm={"dec.conv_pre.weight"}))
+    exe = tmp_path / "fuzz_onnx"
+    csrc = os.path.join(root, "piper-swift_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tools", "fuzz", "fuzz_onnx.cpp"),
+                           os.path.join(csrc, "onnx_loader.cpp"), os.path.join(csrc, "voice_blob.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe), str(seed), "1500"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no sanitizer report" in out.stdout
