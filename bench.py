@@ -227,7 +227,7 @@ def main():
             out["top_launches"] = [{"name": s["name"], "us": round(s["avg_us"], 2),
                                     "tflops": round(s["flops"] / (s["avg_us"] * 1e-6) / 1e12, 2) if s["avg_us"] > 0 else 0} for s in top]
         # ---- the reference's scale bench: factor 1,2,4,8 latency (warmup 3, iters 20)
-        if not args.no_scale_bench:
+        if not args.no_scale_bench and world == 1:  # single-GPU side metric: other ranks would only wait
             rows = []
             for f in (1, 2, 4, 8):
                 i2, d2, n2 = utterance(f, 99 + f, cfg.inter)
@@ -267,7 +267,7 @@ def main():
             out["batch_throughput"] = {"slots_in_flight": S, "utterances_per_sec": round(reps * S / dt, 1),
                                        "audio_sec_per_wall_sec": round(reps * S * audio_sec / dt, 1)}
         # ---- same-shape batching: N utterances per launch share one schedule (batch dimension in every kernel)
-        if not args.no_scale_bench:
+        if not args.no_scale_bench and world == 1:  # single-GPU side metric: other ranks would only wait
             NBATCH = 8
             bu = [utterance(args.factor, 700 + b, cfg.inter) for b in range(NBATCH)]
             for sl in (14, 15):
@@ -347,7 +347,7 @@ def main():
                                                        "audio_sec_per_wall_sec": round(b_audio / dt2, 1)}
                 rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
         # ---- streaming (synthesizeStream): time to the first audio chunk vs the whole utterance, long-form input
-        if not args.no_scale_bench:
+        if not args.no_scale_bench and world == 1:  # single-GPU side metric: other ranks would only wait
             sf, chunk = 64, 64
             si, sd, sn = utterance(sf, 4242, cfg.inter)
             for _ in range(2):  # builds and caches the schedules / graphs of the three window widths
