@@ -36,241 +36,7 @@ def subsample(a):
     return a[::step].copy()
 
 
-def t(a):
-    return torch.from_numpy(np.ascontiguousarray(a))
-
-
-# ------------------------------------------------------------------ torch reference model (Piper VITS, infer path)
-class Ref:
-    def __init__(self, cfg, blob):
-        self.cfg = cfg
-        self.w = {e["name"]: t(blob[e["offset"]:e["offset"] + e["count"]].reshape(e["shape"])) for e in ph.blob_layout(cfg)}
-
-    def conv(self, name, x, pad=(0, 0), dil=1):
-        x = Fn.pad(x, pad)
-        return Fn.conv1d(x, self.w[name + ".weight"], self.w.get(name + ".bias"), dilation=dil)
-
-    @staticmethod
-    def rel_embeddings(emb, T, window):
-        pad_length = max(T - (window + 1), 0)
-        start = max((window + 1) - T, 0)
-        e = emb.unsqueeze(0)
-        if pad_length > 0:
-            e = Fn.pad(e, [0, 0, pad_length, pad_length, 0, 0])
-        return e[:, start:start + 2 * T - 1]
-
-    @staticmethod
-    def rel_to_abs(x):
-        b, h, L, _ = x.shape
-        x = Fn.pad(x, [0, 1])
-        x = x.reshape(b, h, L * 2 * L)
-        x = Fn.pad(x, [0, L - 1])
-        return x.reshape(b, h, L + 1, 2 * L - 1)[:, :, :L, L - 1:]
-
-    @staticmethod
-    def abs_to_rel(x):
-        b, h, L, _ = x.shape
-        x = Fn.pad(x, [0, L - 1])
-        x = x.reshape(b, h, L * (2 * L - 1))
-        x = Fn.pad(x, [L, 0])
-        return x.reshape(b, h, L, 2 * L)[:, :, :, 1:]
-
-    @classmethod
-    def attention(cls, q, k, v, ek, ev, heads, window):
-        b, C, T = q.shape
-        d = C // heads
-        q = q.view(b, heads, d, T).transpose(2, 3)
-        k = k.view(b, heads, d, T).transpose(2, 3)
-        v = v.view(b, heads, d, T).transpose(2, 3)
-        qs = q / (d ** 0.5)
-        scores = torch.matmul(qs, k.transpose(-2, -1))
-        rk = cls.rel_embeddings(ek, T, window)
-        scores = scores + cls.rel_to_abs(torch.matmul(qs, rk.unsqueeze(0).transpose(-2, -1)))
-        p = Fn.softmax(scores, dim=-1)
-        out = torch.matmul(p, v)
-        rv = cls.rel_embeddings(ev, T, window)
-        out = out + torch.matmul(cls.abs_to_rel(p), rv.unsqueeze(0))
-        return out.transpose(2, 3).contiguous().view(b, C, T)
-
-    @staticmethod
-    def layernorm(x, g, b, eps=1e-5):
-        return Fn.layer_norm(x.transpose(1, -1), (x.shape[1],), g, b, eps).transpose(1, -1)
-
-    def text_encoder(self, ids):
-        c = self.cfg
-        x = self.w["enc_p.emb.weight"][t(np.asarray(ids, np.int64))] * (c.hidden ** 0.5)
-        x = x.unsqueeze(0).transpose(1, 2)
-        for l in range(c.n_layers):
-            P = f"enc_p.encoder.attn_layers.{l}."
-            q, k, v = (self.conv(P + n, x) for n in ("conv_q", "conv_k", "conv_v"))
-            y = self.attention(q, k, v, self.w[P + "emb_rel_k"], self.w[P + "emb_rel_v"], c.n_heads, c.window)
-            y = self.conv(P + "conv_o", y)
-            x = self.layernorm(x + y, self.w[f"enc_p.encoder.norm_layers_1.{l}.gamma"], self.w[f"enc_p.encoder.norm_layers_1.{l}.beta"])
-            kf = c.ffn_kernel
-            pad = ((kf - 1) // 2, kf // 2)
-            y = torch.relu(self.conv(f"enc_p.encoder.ffn_layers.{l}.conv_1", x, pad))
-            y = self.conv(f"enc_p.encoder.ffn_layers.{l}.conv_2", y, pad)
-            x = self.layernorm(x + y, self.w[f"enc_p.encoder.norm_layers_2.{l}.gamma"], self.w[f"enc_p.encoder.norm_layers_2.{l}.beta"])
-        return x, self.conv("enc_p.proj", x)
-
-    @staticmethod
-    def wn_layer(x, skip, w_in, b_in, w_rs, b_rs, K, dil, last):
-        C = x.shape[1]
-        pad = (K * dil - dil) // 2
-        xin = Fn.conv1d(x, w_in, b_in, dilation=dil, padding=pad)
-        acts = torch.tanh(xin[:, :C]) * torch.sigmoid(xin[:, C:])
-        rs = Fn.conv1d(acts, w_rs, b_rs)
-        if skip is None:
-            skip = torch.zeros_like(x)
-        if last:
-            return None, skip + rs
-        return x + rs[:, :C], skip + rs[:, C:]
-
-    def flow_reverse(self, x):
-        c = self.cfg
-        half = c.inter // 2
-        for f in reversed(range(c.n_flows)):
-            x = torch.flip(x, [1])
-            x0, x1 = x[:, :half], x[:, half:]
-            P = f"flow.flows.{2 * f}."
-            h = self.conv(P + "pre", x0)
-            skip = None
-            for i in range(c.wn_layers):
-                last = i + 1 == c.wn_layers
-                hn, skip = self.wn_layer(h, skip, self.w[P + f"enc.in_layers.{i}.weight"], self.w[P + f"enc.in_layers.{i}.bias"],
-                                         self.w[P + f"enc.res_skip_layers.{i}.weight"], self.w[P + f"enc.res_skip_layers.{i}.bias"],
-                                         c.wn_kernel, 1, last)
-                if not last:
-                    h = hn
-            m = self.conv(P + "post", skip)
-            x = torch.cat([x0, x1 - m], 1)
-        return x
-
-    @staticmethod
-    def resblock(type_, x, K, dils, ws, bs, slope=0.1):
-        for i, d in enumerate(dils):
-            if type_ == 1:
-                xt = Fn.conv1d(Fn.leaky_relu(x, slope), ws[2 * i], bs[2 * i], dilation=d, padding=(K * d - d) // 2)
-                xt = Fn.conv1d(Fn.leaky_relu(xt, slope), ws[2 * i + 1], bs[2 * i + 1], padding=(K - 1) // 2)
-            else:
-                xt = Fn.conv1d(Fn.leaky_relu(x, slope), ws[i], bs[i], dilation=d, padding=(K * d - d) // 2)
-            x = xt + x
-        return x
-
-    def generator(self, z):
-        c = self.cfg
-        x = self.conv("dec.conv_pre", z, (3, 3))
-        for u in range(c.n_ups):
-            x = Fn.leaky_relu(x, 0.1)
-            k, s = c.up_kernels[u], c.up_rates[u]
-            x = Fn.conv_transpose1d(x, self.w[f"dec.ups.{u}.weight"], self.w[f"dec.ups.{u}.bias"], stride=s, padding=(k - s) // 2)
-            xs = None
-            for j in range(c.n_rb):
-                rb = u * c.n_rb + j
-                dils = [c.rb_dilations[j][d] for d in range(c.rb_n_dil)]
-                if c.resblock_type == 1:
-                    ws, bs = [], []
-                    for d in range(c.rb_n_dil):
-                        for cn in ("convs1", "convs2"):
-                            ws.append(self.w[f"dec.resblocks.{rb}.{cn}.{d}.weight"])
-                            bs.append(self.w[f"dec.resblocks.{rb}.{cn}.{d}.bias"])
-                else:
-                    ws = [self.w[f"dec.resblocks.{rb}.convs.{d}.weight"] for d in range(c.rb_n_dil)]
-                    bs = [self.w[f"dec.resblocks.{rb}.convs.{d}.bias"] for d in range(c.rb_n_dil)]
-                r = self.resblock(c.resblock_type, x, c.rb_kernels[j], dils, ws, bs)
-                xs = r if xs is None else xs + r
-            x = xs / c.n_rb
-        x = Fn.leaky_relu(x)
-        x = Fn.conv1d(x, self.w["dec.conv_post.weight"], None, padding=3)
-        return torch.tanh(x)
-
-    def synthesize(self, ids, durations, noise, noise_scale):
-        c = self.cfg
-        enc, stats = self.text_encoder(ids)
-        m_p, logs_p = stats[:, :c.inter], stats[:, c.inter:]
-        T, F = len(ids), int(np.sum(durations))
-        attn = torch.zeros(1, F, T)
-        f = 0
-        for i, dcount in enumerate(durations):
-            attn[0, f:f + dcount, i] = 1.0
-            f += dcount
-        m_e = torch.matmul(attn, m_p.transpose(1, 2)).transpose(1, 2)
-        l_e = torch.matmul(attn, logs_p.transpose(1, 2)).transpose(1, 2)
-        z_p = m_e + t(noise).reshape(1, c.inter, F) * torch.exp(l_e) * noise_scale
-        z = self.flow_reverse(z_p)
-        o = self.generator(z)
-        return dict(enc_out=enc, m_p=m_p, logs_p=logs_p, z_p=z_p, z=z, audio=o.reshape(-1))
-
-
-# ------------------------------------------------------------------ HF cross-checks (generation time only)
-def hf_crosscheck(cfg_m, blob_m, cfg_h, blob_h):
-    os.environ["HF_HUB_OFFLINE"] = "1"
-    from transformers.models.vits import modeling_vits as mv
-    from transformers.models.vits.configuration_vits import VitsConfig
-    rep = {}
-    hc = VitsConfig()  # defaults = Piper "high" decoder geometry, hidden 192, 2 heads, window 4
-    ref_m, ref_h = Ref(cfg_m, blob_m), Ref(cfg_h, blob_h)
-    with torch.no_grad():
-        # attention + encoder layer 0
-        lay = mv.VitsEncoderLayer(hc).eval()
-        P = "enc_p.encoder.attn_layers.0."
-        for hn, pn in (("q_proj", "conv_q"), ("k_proj", "conv_k"), ("v_proj", "conv_v"), ("out_proj", "conv_o")):
-            getattr(lay.attention, hn).weight.copy_(ref_m.w[P + pn + ".weight"][:, :, 0])
-            getattr(lay.attention, hn).bias.copy_(ref_m.w[P + pn + ".bias"])
-        lay.attention.emb_rel_k.copy_(ref_m.w[P + "emb_rel_k"].unsqueeze(0))
-        lay.attention.emb_rel_v.copy_(ref_m.w[P + "emb_rel_v"].unsqueeze(0))
-        lay.layer_norm.weight.copy_(ref_m.w["enc_p.encoder.norm_layers_1.0.gamma"])
-        lay.layer_norm.bias.copy_(ref_m.w["enc_p.encoder.norm_layers_1.0.beta"])
-        lay.final_layer_norm.weight.copy_(ref_m.w["enc_p.encoder.norm_layers_2.0.gamma"])
-        lay.final_layer_norm.bias.copy_(ref_m.w["enc_p.encoder.norm_layers_2.0.beta"])
-        for hn, pn in (("conv_1", "conv_1"), ("conv_2", "conv_2")):
-            getattr(lay.feed_forward, hn).weight.copy_(ref_m.w[f"enc_p.encoder.ffn_layers.0.{pn}.weight"])
-            getattr(lay.feed_forward, hn).bias.copy_(ref_m.w[f"enc_p.encoder.ffn_layers.0.{pn}.bias"])
-        for T in (3, 14, 40):
-            x = t(kd.sym(99 + T, (1, 192, T)))
-            q, k, v = (ref_m.conv(P + n, x) for n in ("conv_q", "conv_k", "conv_v"))
-            mine = ref_m.conv(P + "conv_o", Ref.attention(q, k, v, ref_m.w[P + "emb_rel_k"], ref_m.w[P + "emb_rel_v"], 2, 4))
-            theirs, _ = lay.attention(x.transpose(1, 2))
-            rep[f"attention_T{T}"] = float((mine - theirs.transpose(1, 2)).abs().max())
-            # whole layer
-            one = torch.ones(1, T, 1)
-            theirs = lay(x.transpose(1, 2), one)[0].transpose(1, 2)
-            y = ref_m.layernorm(x + mine, lay.layer_norm.weight, lay.layer_norm.bias)
-            f1 = torch.relu(ref_m.conv("enc_p.encoder.ffn_layers.0.conv_1", y, (1, 1)))
-            f2 = ref_m.conv("enc_p.encoder.ffn_layers.0.conv_2", f1, (1, 1))
-            mine2 = ref_m.layernorm(y + f2, lay.final_layer_norm.weight, lay.final_layer_norm.bias)
-            rep[f"encoder_layer_T{T}"] = float((mine2 - theirs).abs().max())
-        # flow
-        blk = mv.VitsResidualCouplingBlock(hc).eval()
-        for f in range(4):
-            L = blk.flows[f]
-            P = f"flow.flows.{2 * f}."
-            L.conv_pre.weight.copy_(ref_m.w[P + "pre.weight"]); L.conv_pre.bias.copy_(ref_m.w[P + "pre.bias"])
-            L.conv_post.weight.copy_(ref_m.w[P + "post.weight"]); L.conv_post.bias.copy_(ref_m.w[P + "post.bias"])
-            for i in range(4):
-                for lst, nm in ((L.wavenet.in_layers, "in_layers"), (L.wavenet.res_skip_layers, "res_skip_layers")):
-                    torch.nn.utils.parametrize.remove_parametrizations(lst[i], "weight")
-                    lst[i].weight.copy_(ref_m.w[P + f"enc.{nm}.{i}.weight"])
-                    lst[i].bias.copy_(ref_m.w[P + f"enc.{nm}.{i}.bias"])
-        zp = t(kd.sym(77, (1, 192, 20)))
-        rep["flow_reverse"] = float((ref_m.flow_reverse(zp) - blk(zp, torch.ones(1, 1, 20), reverse=True)).abs().max())
-        # HiFi-GAN (high geometry = VitsConfig defaults)
-        gen = mv.VitsHifiGan(hc).eval()
-        gen.conv_pre.weight.copy_(ref_h.w["dec.conv_pre.weight"]); gen.conv_pre.bias.copy_(ref_h.w["dec.conv_pre.bias"])
-        for u in range(4):
-            gen.upsampler[u].weight.copy_(ref_h.w[f"dec.ups.{u}.weight"]); gen.upsampler[u].bias.copy_(ref_h.w[f"dec.ups.{u}.bias"])
-        for rb in range(12):
-            for d in range(3):
-                for cn, lst in (("convs1", gen.resblocks[rb].convs1), ("convs2", gen.resblocks[rb].convs2)):
-                    lst[d].weight.copy_(ref_h.w[f"dec.resblocks.{rb}.{cn}.{d}.weight"])
-                    lst[d].bias.copy_(ref_h.w[f"dec.resblocks.{rb}.{cn}.{d}.bias"])
-        gen.conv_post.weight.copy_(ref_h.w["dec.conv_post.weight"])
-        z = t(kd.sym(55, (1, 192, 4)))
-        rep["hifigan_high"] = float((ref_h.generator(z) - gen(z)).abs().max())
-    for k, v in rep.items():
-        print(f"  HF cross-check {k}: max|Δ| = {v:.3e}")
-        assert v < 2e-4, (k, v)
-    return rep
+from torch_ref import Ref, hf_crosscheck, t  # noqa: E402  (tests/torch_ref.py: the torch model + its HF cross-check)
 
 
 def main():
