@@ -48,6 +48,79 @@ def percentile(xs, p):  # PiperCLI.swift:425-436
     return s[f] if f == c else s[f] + (s[c] - s[f]) * (k - f)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without torchrun: this process never touches the GPU (no HIP call, no torch.cuda, not even
+    an `import torch`); it starts N children — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — relays rank 0's
+    single JSON line and fails if any rank fails. (A process that has initialised the GPU must not exec or fork workers.)"""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if any(rcs) or len(lines) != 1:
+        sys.stderr.write(f"bench.py: ranks exited with {rcs}; rank 0 printed {len(lines)} JSON line(s)\n")
+        raise SystemExit(1)
+    print(lines[0], flush=True)
+
+
+def dry_run(args, rank, world, saved_stdout):
+    """PIPER_BENCH_DRY=1: the multi-rank control flow on CPUs over gloo — rendezvous, one-shot blob broadcast, LPT shard of
+    the batch-32 config, barrier-bracketed timed region, MAX over ranks, per-rank gather, ONE line from rank 0 — with a
+    stand-in for the GPU work (no HIP, no kernels, `value` meaningless). Exists so tests/ can exercise `--gpus N`'s
+    launcher and aggregation on a box without GPUs; never a measurement."""
+    import torch
+    import torch.distributed as dist
+    import piper_hip as ph
+    from piper_hip import distributed as phd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ph.voice_config(args.quality)
+    n = ph.blob_floats(cfg)
+    blob = torch.from_numpy(ph.synthetic_blob(cfg, 1234)) if rank == 0 else torch.zeros(n, dtype=torch.float32)
+    dist.barrier()
+    t0 = time.perf_counter()
+    phd.broadcast_blob(blob, src=0)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    digest = float(blob[::4099].double().sum())
+    factors = phd.batch32_factors()
+    mine = phd.shard_utterances([14 * f for f in factors], world)[rank]
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))  # stand-in: rank r "takes" r+1 ms per step
+    dist.barrier()
+    elapsed = phd.max_over_ranks(time.perf_counter() - t0)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "utterances": len(mine), "ids": int(sum(14 * factors[i] for i in mine)),
+                                      "blob_digest": digest})
+    if rank == 0:
+        out = {"metric": "DRY RUN (gloo, no GPU work) — launcher / aggregation rehearsal only", "value": 0.0,
+               "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True, "world_size_reported": dist.get_world_size(),
+               "weight_broadcast_ms": round(bcast_ms, 3), "batch32_per_rank": per_rank,
+               "config": {"workload": "dry run", "parallelism": f"utterance-replicas x{world}"}}
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +136,12 @@ def main():
     ap.add_argument("--slots", type=int, default=8, help="utterances in flight for the batch-throughput side metric")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: be the launcher (before anything in this process touches the GPU)
+        return launch_ranks(args.gpus, sys.argv[1:])
+
     # stdout carries exactly ONE line (the JSON): anything libraries print (RCCL's version banner, …) goes to stderr
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -71,11 +150,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}, "
+                         f"or plain `python bench.py --gpus {args.gpus}` (it starts the ranks itself)")
+    if os.environ.get("PIPER_BENCH_DRY") == "1":
+        return dry_run(args, rank, world, saved_stdout)
     # PIPER_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, device-resident broadcast blob, MAX all-reduce)
     # with a single rank — the only way to rehearse it on a one-GPU box
     distributed = world > 1 or os.environ.get("PIPER_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and distributed:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import piper_hip as ph
     if distributed:
@@ -169,8 +251,52 @@ def main():
         "gpu_ms_mean": round(float(np.mean(gpu_ms)), 4),
     }
     if bcast_ms is not None:
+        import torch.distributed as dist
         out["weight_broadcast_ms"] = round(bcast_ms, 3)
         out["weight_blob_mb"] = round(n_floats * 4 / 1e6, 1)
+        out["world_size_reported"] = dist.get_world_size()  # what RCCL's communicator says, not what --gpus asked for
+
+    # ---- BASELINE configs[3]: the 32 mixed-length utterances, LPT-sharded over the ranks (all 32 on one GPU when N = 1).
+    # EVERY rank runs its shard inside the same barrier bracket; the batch time is the MAX over ranks.
+    batch32 = None
+    if not args.no_scale_bench:
+        from piper_hip import distributed as phd
+        factors = phd.batch32_factors()
+        mine = phd.shard_utterances([14 * f for f in factors], world)[rank]
+        by_factor = {}
+        for i in mine:
+            by_factor.setdefault(factors[i], []).append(i)
+        groups = sorted(by_factor.items())
+        for sl, (f, idxs) in enumerate(groups):  # one schedule per distinct shape, batch = utterances of that shape
+            rt.prepare_batch(sl, [utterance(f, 3000 + 17 * f + k, cfg.inter) for k in range(len(idxs))], 0.667)
+
+        def run_bucketed():
+            for sl in range(len(groups)):
+                rt.launch(sl)
+            for sl in range(len(groups)):
+                rt.collect(sl, want_audio=False)
+        run_bucketed()
+        reps = 5
+        barrier()
+        a = time.perf_counter()
+        for _ in range(reps):
+            run_bucketed()
+        barrier()
+        dt = (time.perf_counter() - a) / reps
+        my_audio = sum(14 * factors[i] * 3 * hop / sr for i in mine)
+        mine_row = {"rank": rank, "utterances": len(mine), "ids": int(sum(14 * factors[i] for i in mine)), "launches": len(groups),
+                    "audio_sec": round(my_audio, 2), "ms_per_batch": round(dt * 1e3, 3)}
+        rows = [mine_row]
+        if distributed:
+            dt = phd.max_over_ranks(dt, device="cuda")
+            rows = phd.gather_rows(mine_row)
+        tot_audio = sum(14 * f * 3 * hop / sr for f in factors)
+        batch32 = {"utterances": 32, "audio_sec": round(tot_audio, 2), "ms_per_batch": round(dt * 1e3, 3),
+                   "utterances_per_sec": round(32 / dt, 1), "audio_sec_per_wall_sec": round(tot_audio / dt, 1),
+                   "per_rank": rows,
+                   "note": "32 mixed-length utterances (factors 1..16), LPT-sharded over ranks, one prepare_batch schedule per shape "
+                           "per rank, all ranks inside one barrier bracket, MAX over ranks"}
+        rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
 
     if rank == 0:
         # ---- roofline of the dominant kernel, measured live with HIP events on the slot's stream
@@ -286,66 +412,6 @@ def main():
             out["batched_same_shape"] = {"batch": NBATCH, "slots_in_flight": 2, "utterances_per_sec": round(reps * 2 * NBATCH / dt, 1),
                                          "audio_sec_per_wall_sec": round(reps * 2 * NBATCH * audio_sec / dt, 1),
                                          "conv_kernel_tflops": round(fl_b / (us_b * n_b * 1e-6) / 1e12, 2) if us_b > 0 else None}
-        # ---- BASELINE configs[3]: the 32 mixed-length utterances (this rank's LPT shard; all 32 on one GPU), overlapped on slots
-        if not args.no_scale_bench:
-            from piper_hip import distributed as phd
-            factors = phd.batch32_factors()
-            mine = phd.shard_utterances([14 * f for f in factors], world)[rank]
-            by_factor = {}
-            for i in mine:
-                by_factor.setdefault(factors[i], []).append(i)
-            slot_of, nslot = {}, 0
-            for f, idxs in sorted(by_factor.items()):  # ≤ 2 slots per distinct shape, ≤ 16 slots in all
-                for k in range(min(2, len(idxs))):
-                    if nslot < 16:
-                        i2, d2, n2 = utterance(f, 3000 + 17 * f + k, cfg.inter)
-                        rt.prepare(nslot, i2, d2, n2, 0.667)
-                        slot_of.setdefault(f, []).append(nslot)
-                        nslot += 1
-            plan = []  # (slot, factor) in launch order: every utterance of the shard exactly once
-            for f, idxs in by_factor.items():
-                for k, _ in enumerate(idxs):
-                    plan.append((slot_of[f][k % len(slot_of[f])], f))
-            b_audio = sum(14 * f * 3 * hop / sr for _, f in plan)
-
-            def run_batch():
-                busy = set()
-                for sl, _ in plan:
-                    if sl in busy:  # same graph/arena again: wait for its previous utterance first
-                        rt.collect(sl, want_audio=False)
-                    rt.launch(sl)
-                    busy.add(sl)
-                for sl in busy:
-                    rt.collect(sl, want_audio=False)
-            run_batch()
-            reps = 5
-            a = time.perf_counter()
-            for _ in range(reps):
-                run_batch()
-            dt = (time.perf_counter() - a) / reps
-            out["batch32"] = {"utterances": len(plan), "audio_sec": round(b_audio, 2), "ms_per_batch": round(dt * 1e3, 3),
-                              "utterances_per_sec": round(len(plan) / dt, 1), "audio_sec_per_wall_sec": round(b_audio / dt, 1),
-                              "slots": nslot, "note": "32 mixed-length utterances (factors 1..16), LPT-sharded over ranks, graphs cached per shape"}
-            # the same shard bucketed by shape: utterances of equal (T, F) go through ONE schedule (prepare_batch), one slot per shape
-            groups = sorted(by_factor.items())
-            if len(groups) <= 16 and any(len(ix) > 1 for _, ix in groups):
-                for sl, (f, idxs) in enumerate(groups):
-                    rt.prepare_batch(sl, [utterance(f, 3000 + 17 * f + k, cfg.inter) for k in range(len(idxs))], 0.667)
-
-                def run_bucketed():
-                    for sl in range(len(groups)):
-                        rt.launch(sl)
-                    for sl in range(len(groups)):
-                        rt.collect(sl, want_audio=False)
-                run_bucketed()
-                a = time.perf_counter()
-                for _ in range(reps):
-                    run_bucketed()
-                dt2 = (time.perf_counter() - a) / reps
-                out["batch32"]["bucketed_by_shape"] = {"launches": len(groups), "ms_per_batch": round(dt2 * 1e3, 3),
-                                                       "utterances_per_sec": round(len(plan) / dt2, 1),
-                                                       "audio_sec_per_wall_sec": round(b_audio / dt2, 1)}
-                rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
         # ---- streaming (synthesizeStream): time to the first audio chunk vs the whole utterance, long-form input
         if not args.no_scale_bench and world == 1:  # single-GPU side metric: other ranks would only wait
             sf, chunk = 64, 64
@@ -389,6 +455,8 @@ def main():
             out["cpu_baseline"] = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
                                    "cores": cores, "kind": "port",
                                    "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
+        if batch32 is not None:
+            out["batch32"] = batch32
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -52,3 +52,22 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+_meta_group = None
+
+
+def gather_rows(row):
+    """Every rank's small metadata dict on every rank (list indexed by rank). Goes over a gloo side group so that the RCCL
+    communicator only ever carries the weight broadcast and the scalar reductions."""
+    global _meta_group
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        grp = None
+    else:
+        if _meta_group is None:
+            _meta_group = dist.new_group(backend="gloo")
+        grp = _meta_group
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, row, group=grp)
+    return out

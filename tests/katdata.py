@@ -125,7 +125,7 @@ BINARY_CASES = [
 
 def case_seed(kind, idx):
     return 1234 + 7919 * idx + {"conv": 0, "convt": 100003, "mm": 200003, "sm": 300007, "bin": 400009, "un": 500009,
-                                "mod": 600011}[kind]
+                                "mod": 600011, "cfg": 700001, "rng": 800011, "dp": 900001}[kind]
 
 
 def conv1d_inputs(idx):

@@ -70,3 +70,31 @@ def test_lpt_partition_balance():
         assert sorted(i for sh in shards for i in sh) == list(range(32))
     # 8 GPUs: every rank gets 364 ids (one utterance of each factor group)
     assert set(sum(14 * factors[i] for i in sh) for sh in phd.shard_utterances([14 * f for f in factors], 8)) == {364}
+
+
+def test_bench_launcher_spawns_ranks_dry():
+    """`python bench.py --gpus 2` WITHOUT torchrun must start two ranks itself and print ONE line with n_gpus = 2
+    (round-1 defect: it silently measured one GPU). PIPER_BENCH_DRY=1 swaps the GPU work for a stand-in and RCCL for
+    gloo, so the launcher, the rendezvous, the broadcast, the sharding and the aggregation run here without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIPER_BENCH_DRY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_reported"] == 2 and out["dry_run"] is True
+    assert out["ms_per_step"] >= 2.0  # MAX over ranks: rank 1's stand-in takes 2 ms per step
+    rows = out["batch32_per_rank"]
+    assert [r_["rank"] for r_ in rows] == [0, 1] and sum(r_["utterances"] for r_ in rows) == 32
+    assert rows[0]["blob_digest"] == rows[1]["blob_digest"] != 0.0  # rank 1 received rank 0's weights
+    # a mismatching WORLD_SIZE is an error, not a silent single-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
