@@ -328,6 +328,10 @@ typedef struct {
   float noise_scale, length_scale, noise_w;
 } piper_hip_piper_json_info;
 int piper_hip_piper_json(const char* json_text, piper_hip_piper_json_info* out);
+/* Is the voice the `.onnx.json` describes one this library renders correctly with geometry `cfg`? ERR_UNSUPPORTED for
+ * num_speakers > 1 (speaker conditioning is not implemented: the audio would be wrong without any error), ERR_SHAPE when
+ * num_symbols differs from the embedding rows of the graph. */
+int piper_hip_voice_check_json(const piper_hip_voice_config* cfg, const piper_hip_piper_json_info* info);
 
 /* Waveform → 16-bit PCM / mono WAV (WavFileWriter.swift:20-30, 44-60): clamp to [−1,1], ×32767, truncate toward zero. */
 int piper_hip_pcm16_from_f32(const float* samples, size_t n, int16_t* pcm);

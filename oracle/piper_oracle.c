@@ -798,8 +798,9 @@ static T orc_text_encoder(const blob_index* bi, const int64_t* ids, long T_, T* 
   T e = t_new(3, 1, T_, H, 1);
   for (long t = 0; t < T_; t++) {
     long id = ids[t];
-    if (id < 0 || id >= c->n_vocab) id = 0;
-    memcpy(e.d + t * H, emb + id * H, (size_t)H * sizeof(float));
+    if (id < 0) id += c->n_vocab; /* gather.metal:54-57: negative ids wrap once, anything still out of range reads 0.0 */
+    if (id < 0 || id >= c->n_vocab) memset(e.d + t * H, 0, (size_t)H * sizeof(float));
+    else memcpy(e.d + t * H, emb + id * H, (size_t)H * sizeof(float));
   }
   T sc = t_scalar(sqrtf((float)H));
   T es = t_binary(2, &e, &sc);

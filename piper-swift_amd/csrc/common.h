@@ -34,9 +34,12 @@ const char* get_error();
     if (_e != hipSuccess) PH_FAIL(code, "%s failed: %s", #expr, hipGetErrorString(_e));       \
   } while (0)
 
-#define PH_CHECK_CTX(ctx)                                      \
-  do {                                                         \
-    if (!(ctx)) PH_FAIL(PIPER_HIP_ERR_ARG, "null context");    \
+// Every entry point that takes a context runs on THAT context's device, whatever the calling thread's current device is
+// (two contexts in one process, or a context used from a second host thread).
+#define PH_CHECK_CTX(ctx)                                                                                                   \
+  do {                                                                                                                      \
+    if (!(ctx)) PH_FAIL(PIPER_HIP_ERR_ARG, "null context");                                                                 \
+    if (hipSetDevice((ctx)->device) != hipSuccess) PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "hipSetDevice(%d) failed", (ctx)->device); \
   } while (0)
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -48,11 +51,33 @@ struct Pool {
   std::mutex mu;
   std::unordered_map<void*, size_t> live;            // ptr -> bucket bytes
   std::map<size_t, std::vector<void*>> free_blocks;  // bucket bytes -> ptrs
+  // Blocks freed by the HOST while work may still be queued on the context's streams: each carries one event per stream,
+  // recorded at free time; the block goes back on the free list only once all of them have completed (stream-ordered free).
+  struct Pending {
+    void* p;
+    size_t bucket;
+    std::vector<hipEvent_t> evs;
+  };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_cache;
   size_t bytes_reserved = 0;
   int alloc(size_t bytes, void** out);
-  int release(void* p);  // returns PIPER_HIP_ERR_ARG if p is not a live pool block
+  int release(void* p);  // immediate reuse: only for blocks whose users are known to be complete
+  // stream-ordered release: reusable once everything enqueued so far on `streams` has run
+  int release_after(void* p, const std::vector<hipStream_t>& streams);
+  void reap(bool wait);  // move completed pending blocks to the free list (wait = block until all are complete)
   void trim();
 };
+
+// per-device "already opted in to > 64 KiB of dynamic LDS" flags (hipFuncSetAttribute is per device)
+constexpr int kMaxDevices = 64;
+inline bool lds_optin_needed(bool (&flags)[kMaxDevices]) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return true;
+  if (flags[d]) return false;
+  flags[d] = true;
+  return true;
+}
 
 }  // namespace ph
 
@@ -60,6 +85,7 @@ struct piper_hip_ctx {
   int device = 0;
   hipDeviceProp_t props{};
   hipStream_t default_stream = nullptr;  // used when the caller passes stream == NULL (blocking semantics)
+  std::vector<hipStream_t> streams;      // default_stream + every stream handed out by piper_hip_stream_create
   ph::Pool pool;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   int num_cus = 256;

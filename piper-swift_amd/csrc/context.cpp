@@ -20,9 +20,56 @@ static size_t bucket_of(size_t bytes) {
   return b;
 }
 
+void Pool::reap(bool wait) {  // caller holds mu
+  size_t keep = 0;
+  for (size_t i = 0; i < pending.size(); i++) {
+    Pending& pe = pending[i];
+    bool done = true;
+    for (hipEvent_t e : pe.evs) {
+      if (wait) (void)hipEventSynchronize(e);
+      else if (hipEventQuery(e) != hipSuccess) { done = false; break; }
+    }
+    if (!done) {
+      (void)hipGetLastError();  // hipErrorNotReady is not an error
+      if (keep != i) pending[keep] = std::move(pe);
+      keep++;
+      continue;
+    }
+    for (hipEvent_t e : pe.evs) event_cache.push_back(e);
+    free_blocks[pe.bucket].push_back(pe.p);
+  }
+  pending.resize(keep);
+}
+
+int Pool::release_after(void* p, const std::vector<hipStream_t>& streams) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = live.find(p);
+  if (it == live.end()) PH_FAIL(PIPER_HIP_ERR_ARG, "piper_hip_free: %p is not a live buffer of this context", p);
+  Pending pe{p, it->second, {}};
+  for (hipStream_t s : streams) {
+    hipEvent_t e = nullptr;
+    if (!event_cache.empty()) { e = event_cache.back(); event_cache.pop_back(); }
+    else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    if (!e || hipEventRecord(e, s) != hipSuccess) {
+      // cannot order the free behind this stream: fall back to a full stop (correct, slow, never expected)
+      (void)hipGetLastError();
+      if (e) event_cache.push_back(e);
+      (void)hipDeviceSynchronize();
+      for (hipEvent_t q : pe.evs) event_cache.push_back(q);
+      pe.evs.clear();
+      break;
+    }
+    pe.evs.push_back(e);
+  }
+  live.erase(it);
+  pending.push_back(std::move(pe));
+  return PIPER_HIP_OK;
+}
+
 int Pool::alloc(size_t bytes, void** out) {
   const size_t b = bucket_of(bytes < 1 ? 1 : bytes);
   std::lock_guard<std::mutex> lk(mu);
+  if (!pending.empty()) reap(false);
   auto it = free_blocks.find(b);
   if (it != free_blocks.end() && !it->second.empty()) {
     *out = it->second.back();
@@ -34,6 +81,8 @@ int Pool::alloc(size_t bytes, void** out) {
   hipError_t e = hipMalloc(&p, b);
   if (e != hipSuccess) {
     // give cached blocks back to the driver and retry once
+    (void)hipGetLastError();
+    reap(true);
     for (auto& kv : free_blocks) {
       for (void* q : kv.second) (void)hipFree(q);
       bytes_reserved -= kv.first * kv.second.size();
@@ -59,6 +108,9 @@ int Pool::release(void* p) {
 
 void Pool::trim() {
   std::lock_guard<std::mutex> lk(mu);
+  reap(true);
+  for (hipEvent_t e : event_cache) (void)hipEventDestroy(e);
+  event_cache.clear();
   for (auto& kv : free_blocks)
     for (void* q : kv.second) (void)hipFree(q);
   free_blocks.clear();
@@ -127,6 +179,7 @@ PH_EXPORT int piper_hip_create(int device, piper_hip_ctx** out) {
     delete c;
     PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "stream/event creation failed");
   }
+  c->streams.push_back(c->default_stream);
   *out = c;
   return PIPER_HIP_OK;
 }
@@ -137,6 +190,8 @@ PH_EXPORT void piper_hip_destroy(piper_hip_ctx* ctx) {
   (void)hipDeviceSynchronize();
   ph::release_deferred(ctx);
   ctx->pool.trim();
+  for (hipStream_t s : ctx->streams)
+    if (s != ctx->default_stream) (void)hipStreamDestroy(s);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->default_stream) (void)hipStreamDestroy(ctx->default_stream);
@@ -152,7 +207,10 @@ PH_EXPORT int piper_hip_alloc(piper_hip_ctx* ctx, size_t bytes, void** out) {
 PH_EXPORT int piper_hip_free(piper_hip_ctx* ctx, void* buf) {
   PH_CHECK_CTX(ctx);
   if (!buf) return PIPER_HIP_OK;
-  return ctx->pool.release(buf);
+  // Stream-ordered (the header's promise): kernels already enqueued on any stream of this context may still read or write
+  // `buf`, so it becomes reusable only after an event recorded NOW on each of them has completed. This is the reference's
+  // GraphExecutor pattern — intermediates are dropped while the command buffer is still being encoded (GraphExecutor.swift:216-225).
+  return ctx->pool.release_after(buf, ctx->streams);
 }
 
 PH_EXPORT int piper_hip_upload_f32(piper_hip_ctx* ctx, const float* host, size_t count, float** out) {
@@ -207,12 +265,26 @@ PH_EXPORT int piper_hip_stream_create(piper_hip_ctx* ctx, piper_hip_stream* out)
   if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "null out");
   hipStream_t s;
   PH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
+  {
+    std::lock_guard<std::mutex> lk(ctx->pool.mu);
+    ctx->streams.push_back(s);
+  }
   *out = (piper_hip_stream)s;
   return PIPER_HIP_OK;
 }
 PH_EXPORT int piper_hip_stream_destroy(piper_hip_ctx* ctx, piper_hip_stream s) {
   PH_CHECK_CTX(ctx);
-  if (s) PH_HIP(hipStreamDestroy((hipStream_t)s), PIPER_HIP_ERR_LAUNCH);
+  if (!s) return PIPER_HIP_OK;
+  if ((hipStream_t)s == ctx->default_stream) PH_FAIL(PIPER_HIP_ERR_ARG, "stream_destroy: not a stream of piper_hip_stream_create");
+  // pending frees hold events recorded on this stream: let them complete before the stream goes away
+  PH_HIP(hipStreamSynchronize((hipStream_t)s), PIPER_HIP_ERR_LAUNCH);
+  {
+    std::lock_guard<std::mutex> lk(ctx->pool.mu);
+    ctx->pool.reap(false);
+    for (size_t i = 0; i < ctx->streams.size(); i++)
+      if (ctx->streams[i] == (hipStream_t)s) { ctx->streams.erase(ctx->streams.begin() + i); break; }
+  }
+  PH_HIP(hipStreamDestroy((hipStream_t)s), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;
 }
 PH_EXPORT int piper_hip_stream_sync(piper_hip_ctx* ctx, piper_hip_stream s) {
@@ -257,6 +329,7 @@ PH_EXPORT int piper_hip_memory_trim(piper_hip_ctx* ctx) {
   PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);  // cached blocks may still be referenced by queued work
   ph::release_deferred(ctx);
   std::lock_guard<std::mutex> lk(ctx->pool.mu);
+  ctx->pool.reap(true);
   for (auto& kv : ctx->pool.free_blocks) {
     for (void* q : kv.second) (void)hipFree(q);
     ctx->pool.bytes_reserved -= kv.first * kv.second.size();

@@ -293,11 +293,9 @@ void launch_inst(hipStream_t s, const ConvBf16Multi& a, int batch, dim3 grid, si
 
 template <int MTW, int NTW, int WM>
 void raise_lds() {
-  static bool done = false;  // windows above the 64 KB default need the opt-in (160 KB per CU on gfx950)
-  if (!done) {
+  static bool done[kMaxDevices] = {};  // windows above the 64 KB default need the opt-in (160 KB per CU on gfx950), per device
+  if (lds_optin_needed(done))
     (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<MTW, NTW, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    done = true;
-  }
 }
 
 int launch_cfg(hipStream_t s, const ConvBf16Multi& a, int batch, int MTW, int NTW, int WM, dim3 grid, size_t lds) {

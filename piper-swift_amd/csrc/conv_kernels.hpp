@@ -588,12 +588,10 @@ inline int padded_steps(int Cin, int K, int tm = 32) {
 template <int K, int NT, bool GATE, int PRO, int BT, int TM>
 void launch_one(hipStream_t s, const ConvArgs& a, int nchunks, int mtiles, int ks_log2, int ngroups, dim3 grid, size_t lds) {
   if (lds > 64 * 1024) {  // opt in to > 64 KiB of dynamic LDS once per instantiation
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[kMaxDevices] = {};
+    if (lds_optin_needed(configured))
       (void)hipFuncSetAttribute((const void*)conv_stream_kernel<K, NT, GATE, PRO, BT, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
-      configured = true;
-    }
   }
   hipLaunchKernelGGL((conv_stream_kernel<K, NT, GATE, PRO, BT, TM>), grid, dim3(BT), lds, s, a, nchunks, mtiles, ks_log2, ngroups);
 }
@@ -645,11 +643,9 @@ bool launch_tile_one(hipStream_t s, const ConvArgs& a, int nsteps) {
   const size_t lds = (size_t)(xs_floats + Cfg::A_FLOATS) * sizeof(float);
   if (lds > 160 * 1024) return false;
   if (lds > 64 * 1024) {
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[kMaxDevices] = {};
+    if (lds_optin_needed(configured))
       (void)hipFuncSetAttribute((const void*)conv_tile_kernel<K, MT, NTW, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      configured = true;
-    }
   }
   const int mtiles = (int)ceil_div(a.Cout, 32);
   const int mgroups = (int)ceil_div(mtiles, MT);

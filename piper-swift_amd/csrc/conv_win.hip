@@ -273,11 +273,9 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
 
 template <int WM, int WN, int KS>
 int launch_inst(hipStream_t s, const ConvWinMulti& a, int batch, dim3 grid, size_t lds) {
-  static bool raised = false;
-  if (lds > 64 * 1024 && !raised) {
+  static bool raised[kMaxDevices] = {};  // the opt-in is per device
+  if (lds > 64 * 1024 && lds_optin_needed(raised))
     (void)hipFuncSetAttribute((const void*)conv_win_kernel<WM, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    raised = true;
-  }
   hipLaunchKernelGGL((conv_win_kernel<WM, WN, KS>), grid, dim3(kBT), lds, s, a, batch);
   return PIPER_HIP_OK;
 }

@@ -78,7 +78,7 @@ struct Tensor {
 };
 
 struct ConvNode {  // Conv / ConvTranspose with an initializer as weight
-  std::string op, weight;
+  std::string op, weight, bias, name;
   int64_t stride = 1, dilation = 1, group = 1, pad_l = 0, pad_r = 0;
 };
 
@@ -95,6 +95,7 @@ struct piper_hip_onnx {
   std::vector<Tensor> tensors;
   std::map<std::string, int> by_name;
   std::map<std::string, ConvNode> conv_by_weight;
+  std::map<std::string, ConvNode> conv_by_node;  // by NodeProto.name ("/flow/flows.0/enc/in_layers.0/Conv")
 };
 
 namespace {
@@ -132,7 +133,7 @@ bool parse_tensor(Reader r, Tensor& t) {
 
 bool parse_node(Reader r, piper_hip_onnx* m) {
   std::vector<std::string> inputs;
-  std::string op;
+  std::string op, node_name;
   ConvNode c;
   bool has_pads = false;
   while (!r.at_end()) {
@@ -141,6 +142,9 @@ bool parse_node(Reader r, piper_hip_onnx* m) {
     if (field == 1 && wire == 2) {
       Reader d = r.sub();
       inputs.emplace_back((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 3 && wire == 2) {
+      Reader d = r.sub();
+      node_name.assign((const char*)d.p, (size_t)(d.end - d.p));
     } else if (field == 4 && wire == 2) {
       Reader d = r.sub();
       op.assign((const char*)d.p, (size_t)(d.end - d.p));
@@ -174,7 +178,10 @@ bool parse_node(Reader r, piper_hip_onnx* m) {
   if ((op == "Conv" || op == "ConvTranspose") && inputs.size() >= 2) {
     c.op = op;
     c.weight = inputs[1];
+    if (inputs.size() >= 3) c.bias = inputs[2];
+    c.name = node_name;
     m->conv_by_weight[c.weight] = c;
+    if (!node_name.empty()) m->conv_by_node[node_name] = c;
   }
   return true;
 }
@@ -230,6 +237,55 @@ const Tensor* find(const piper_hip_onnx* m, const std::string& name) {
   return it == m->by_name.end() ? nullptr : &m->tensors[it->second];
 }
 
+// Module path of a layout name → the scope name torch.onnx gives the module's node: attribute accesses are joined by '/',
+// ModuleList indices stay glued to their list with '.' ("flow.flows.0.enc.in_layers.1" → "/flow/flows.0/enc/in_layers.1";
+// the convention behind the reference's own "/enc_p/encoder/attn_layers." node-name match, GraphExecutor.swift:908).
+std::string scope_of(const std::string& module) {
+  std::string out;
+  size_t i = 0;
+  while (i < module.size()) {
+    size_t j = module.find('.', i);
+    if (j == std::string::npos) j = module.size();
+    const std::string part = module.substr(i, j - i);
+    const bool numeric = !part.empty() && part.find_first_not_of("0123456789") == std::string::npos;
+    out += (numeric && !out.empty()) ? "." : "/";
+    out += part;
+    i = j + 1;
+  }
+  return out;
+}
+
+// The Conv / ConvTranspose node of module `module`, if the export kept scope names.
+const ConvNode* node_of(const piper_hip_onnx* m, const std::string& module) {
+  const std::string sc = scope_of(module);
+  auto it = m->conv_by_node.find(sc + "/Conv");
+  if (it == m->conv_by_node.end()) it = m->conv_by_node.find(sc + "/ConvTranspose");
+  return it == m->conv_by_node.end() ? nullptr : &it->second;
+}
+
+// Initializer behind a layout name: by its module-path name; else through the module's node — weight-norm parametrised
+// layers (flow WaveNet, HiFi-GAN) are constant-folded by the exporter into anonymous `onnx::Conv_1234` initializers that
+// only the node's input[1] / input[2] still identify.
+const Tensor* resolve(const piper_hip_onnx* m, const std::string& name) {
+  if (const Tensor* t = find(m, name)) return t;
+  const bool is_w = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+  const bool is_b = name.size() > 5 && name.compare(name.size() - 5, 5, ".bias") == 0;
+  if (!is_w && !is_b) return nullptr;
+  const ConvNode* n = node_of(m, name.substr(0, name.size() - (is_w ? 7 : 5)));
+  if (!n) return nullptr;
+  return find(m, is_w ? n->weight : n->bias);
+}
+
+// strides / dilations of the node that consumes a layout weight (by initializer name, then by scope name)
+const ConvNode* conv_node_for(const piper_hip_onnx* m, const std::string& weight_name) {
+  auto it = m->conv_by_weight.find(weight_name);
+  if (it != m->conv_by_weight.end()) return &it->second;
+  it = m->conv_by_weight.find(weight_name + "_v");
+  if (it != m->conv_by_weight.end()) return &it->second;
+  if (weight_name.size() > 7) return node_of(m, weight_name.substr(0, weight_name.size() - 7));
+  return nullptr;
+}
+
 // floats of a FLOAT tensor (raw little-endian or float_data), TensorValue.swift:45-116
 int read_floats(const Tensor& t, float* dst, size_t n) {
   if (t.dtype != 1) PH_FAIL(PIPER_HIP_ERR_TYPE, "onnx: initializer '%s' has data_type %d, expected FLOAT(1)", t.name.c_str(), t.dtype);
@@ -266,7 +322,7 @@ void fill_visit(const piper_tensor_desc* d, void* user) {
   if (b->rc) return;
   const std::string name = d->name;
   float* dst = b->blob + d->offset;
-  if (const Tensor* t = find(b->m, name)) {
+  if (const Tensor* t = resolve(b->m, name)) {
     // shape check: same element count and, when ranks agree, the same dims
     if ((int)t->dims.size() == d->rank)
       for (int i = 0; i < d->rank; i++)
@@ -374,14 +430,23 @@ PH_EXPORT int piper_hip_onnx_read_f32(const piper_hip_onnx* m, int index, float*
 PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voice_config* cfg) {
   if (!m || !cfg) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
   memset(cfg, 0, sizeof *cfg);
+  // Multi-speaker voices condition the flow, the duration predictor and the generator on a speaker embedding `g`
+  // (emb_g + cond / cond_layer convs). None of that is implemented here, and ignoring it would synthesise the wrong voice
+  // without any error — refuse instead.
+  for (const Tensor& it : m->tensors)
+    if (it.name.compare(0, 5, "emb_g") == 0 || it.name.find(".cond.") != std::string::npos || it.name.find(".cond_layer.") != std::string::npos)
+      PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "onnx: multi-speaker voice (initializer '%s'): speaker conditioning is not implemented", it.name.c_str());
+  for (const Tensor& it : m->tensors)  // geometry fields are int32: refuse dims that would be truncated
+    for (int64_t dm : it.dims)
+      if (dm < 0 || dm > INT32_MAX) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: initializer '%s' has a dimension of %lld", it.name.c_str(), (long long)dm);
   auto need = [&](const std::string& name, size_t rank) -> const Tensor* {
-    const Tensor* t = find(m, name);
+    const Tensor* t = resolve(m, name);
     if (!t) t = find(m, name + "_v");  // weight norm left in
     if (!t) { set_error("onnx: not a Piper VITS voice: initializer '%s' missing", name.c_str()); return nullptr; }
     if (t->dims.size() != rank) { set_error("onnx: initializer '%s' has rank %zu, expected %zu", name.c_str(), t->dims.size(), rank); return nullptr; }
     return t;
   };
-  auto has = [&](const std::string& name) { return find(m, name) || find(m, name + "_v"); };
+  auto has = [&](const std::string& name) { return resolve(m, name) || find(m, name + "_v"); };
   const Tensor* t;
   if (!(t = need("enc_p.emb.weight", 2))) return PIPER_HIP_ERR_ARG;
   cfg->n_vocab = (int32_t)t->dims[0];
@@ -411,9 +476,11 @@ PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voi
     const std::string wn = fmt("dec.ups.%d.weight", cfg->n_ups);
     if (!(t = need(wn, 3))) return PIPER_HIP_ERR_ARG;
     cfg->up_kernels[cfg->n_ups] = (int32_t)t->dims[2];
-    auto it = m->conv_by_weight.find(wn);
+    const ConvNode* cn = conv_node_for(m, wn);
     // the stride lives on the ConvTranspose node; HiFi-GAN's convention K = 2·stride is the fallback
-    cfg->up_rates[cfg->n_ups] = it != m->conv_by_weight.end() ? (int32_t)it->second.stride : (int32_t)(t->dims[2] / 2);
+    const int64_t st = cn ? cn->stride : t->dims[2] / 2;
+    if (st < 1 || st > 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: upsampler %d has stride %lld", cfg->n_ups, (long long)st);
+    cfg->up_rates[cfg->n_ups] = (int32_t)st;
     cfg->n_ups++;
   }
   if (has(fmt("dec.ups.%d.weight", cfg->n_ups))) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "onnx: more than %d upsampling stages", PIPER_HIP_MAX_UPS);
@@ -429,10 +496,11 @@ PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voi
     if (!(t = need(fmt(first, j, 0), 3))) return PIPER_HIP_ERR_ARG;
     cfg->rb_kernels[j] = (int32_t)t->dims[2];
     for (int d = 0; d < cfg->rb_n_dil; d++) {
-      auto it = m->conv_by_weight.find(fmt(first, j, d));
-      static const int fallback1[3] = {1, 3, 5}, fallback2[3] = {1, 3, 5};
-      cfg->rb_dilations[j][d] = it != m->conv_by_weight.end() ? (int32_t)it->second.dilation
-                                                              : (cfg->resblock_type == 1 ? fallback1[d] : fallback2[d]);
+      const ConvNode* cn = conv_node_for(m, fmt(first, j, d));
+      static const int fallback[3] = {1, 3, 5};
+      const int64_t dl = cn ? cn->dilation : fallback[d];
+      if (dl < 1 || dl > 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "onnx: resblock %d conv %d has dilation %lld", j, d, (long long)dl);
+      cfg->rb_dilations[j][d] = (int32_t)dl;
     }
   }
   cfg->sample_rate = 22050;  // lives in the voice's .onnx.json (piper_hip_piper_json), not in the graph
@@ -486,5 +554,14 @@ PH_EXPORT int piper_hip_piper_json(const char* json_text, piper_hip_piper_json_i
     if (json_number(s, "length_scale", &v, inf)) out->length_scale = (float)v;
     if (json_number(s, "noise_w", &v, inf)) out->noise_w = (float)v;
   }
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_check_json(const piper_hip_voice_config* cfg, const piper_hip_piper_json_info* info) {
+  if (!cfg || !info) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (info->num_speakers > 1)
+    PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice has %d speakers: speaker conditioning (emb_g / cond layers) is not implemented", info->num_speakers);
+  if (info->num_symbols != cfg->n_vocab)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "voice json says %d symbols, the graph's embedding has %d rows", info->num_symbols, cfg->n_vocab);
   return PIPER_HIP_OK;
 }

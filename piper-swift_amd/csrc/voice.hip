@@ -45,8 +45,8 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
     const int c = i / T, t = i - c * T;
     int64_t id = ids[t];
-    if (id < 0 || id >= n_vocab) id = 0;  // gather.metal: OOB index → row 0
-    x[i] = emb[id * H + c] * scale;
+    if (id < 0) id += n_vocab;  // gather_axis0_f32_2d (gather.metal:54-57): negative ids wrap once, …
+    x[i] = (id < 0 || id >= n_vocab) ? 0.0f * scale : emb[id * H + c] * scale;  // … what is still out of range gathers 0.0
   }
 }
 
@@ -1214,6 +1214,7 @@ PH_EXPORT int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_c
          PIPER_HIP_ERR_LAUNCH);
   // measure, allocate, pack
   auto fail = [&](int code) {
+    (void)hipStreamSynchronize(s);  // pack kernels / the blob copy may still be running on these blocks
     for (void* q : v->owned) (void)ctx->pool.release(q);
     return code;
   };
@@ -1436,6 +1437,7 @@ PH_EXPORT int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot) {
 
 PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   Slot& s = v->slots[slot];
   PH_HIP(hipEventRecord(s.ev0, s.stream), PIPER_HIP_ERR_LAUNCH);
@@ -1447,6 +1449,7 @@ PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
 
 PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   Slot& s = v->slots[slot];
   if (host_audio) {

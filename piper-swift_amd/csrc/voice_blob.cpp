@@ -67,6 +67,22 @@ int validate_config(const piper_hip_voice_config* c) {
       PH_FAIL(PIPER_HIP_ERR_SHAPE, "upsampler %d: kernel/rate unsupported", u);
   if (c->n_layers < 0 || c->n_flows < 0 || c->wn_layers < 1 || c->n_vocab < 1 || c->window < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "bad counts");
   if (!(c->wn_kernel & 1) || !(c->ffn_kernel >= 1)) PH_FAIL(PIPER_HIP_ERR_SHAPE, "wn_kernel must be odd");
+  // hard bounds: the geometry can come from an untrusted file (piper_hip_onnx_infer_config), and every count below sizes an
+  // allocation or a loop
+  if (c->hidden > 4096 || c->inter > 4096 || c->n_vocab > (1 << 20) || c->n_layers > 64 || c->n_flows > 32 || c->wn_layers > 32 ||
+      c->n_heads > 64 || c->window > 1024 || c->up_initial > 8192)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "voice geometry outside the supported bounds");
+  if (c->ffn < 1 || c->ffn > 16384 || c->ffn_kernel > 15 || !(c->ffn_kernel & 1) || c->wn_kernel < 1 || c->wn_kernel > 15)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "ffn %d / ffn_kernel %d / wn_kernel %d unsupported (kernels must be odd, ≤ 15)", c->ffn, c->ffn_kernel, c->wn_kernel);
+  for (int u = 0; u < c->n_ups; u++)
+    if (c->up_rates[u] > 64 || c->up_kernels[u] > 128) PH_FAIL(PIPER_HIP_ERR_SHAPE, "upsampler %d: rate/kernel too large", u);
+  for (int j = 0; j < c->n_rb; j++) {
+    if (c->rb_kernels[j] < 1 || c->rb_kernels[j] > 15 || !(c->rb_kernels[j] & 1))
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "resblock %d: kernel %d must be odd and ≤ 15", j, c->rb_kernels[j]);
+    for (int d = 0; d < c->rb_n_dil; d++)
+      if (c->rb_dilations[j][d] < 1 || c->rb_dilations[j][d] > 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "resblock %d: dilation %d out of [1,64]", j, c->rb_dilations[j][d]);
+  }
+  if (c->sample_rate < 0 || c->sample_rate > 384000) PH_FAIL(PIPER_HIP_ERR_SHAPE, "sample_rate out of range");
   return PIPER_HIP_OK;
 }
 }  // namespace ph

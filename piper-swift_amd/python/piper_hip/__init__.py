@@ -176,6 +176,7 @@ _PROTOS = {
     "piper_hip_onnx_infer_config": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
     "piper_hip_onnx_build_blob": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
     "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
+    "piper_hip_voice_check_json": (C.c_int, [C.POINTER(VoiceConfig), C.POINTER(PiperJsonInfo)]),
     "piper_hip_pcm16_from_f32": (C.c_int, [c_f32p, C.c_size_t, C.POINTER(C.c_int16)]),
     "piper_hip_wav_write": (C.c_int, [C.c_char_p, c_f32p, C.c_size_t, C.c_int32]),
     "piper_hip_voice_receptive_field": (C.c_int, [c_vp]),
@@ -621,6 +622,7 @@ def load_voice(onnx_path, json_path=None):
         jp = json_path or (str(onnx_path) + ".json")
         if os.path.exists(jp):
             info = piper_json(open(jp, "r", encoding="utf-8").read())
+            _check(load_library().piper_hip_voice_check_json(C.byref(cfg), C.byref(info)))  # multi-speaker / vocabulary mismatch
             cfg.sample_rate = info.sample_rate
         return cfg, m.build_blob(cfg), info
     finally:

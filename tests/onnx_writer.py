@@ -83,13 +83,28 @@ def model(nodes, initializers, opset=15, ir_version=8, extra_unknown=True):
     return m
 
 
-def piper_voice_onnx(cfg, blob, layout, weight_norm=(), encodings=("raw", "float_data")):
+def scope_of(module):
+    """torch.onnx scope name of a module path: 'flow.flows.0.enc.in_layers.1' → '/flow/flows.0/enc/in_layers.1'."""
+    out = ""
+    for part in module.split("."):
+        out += ("." if part.isdigit() and out else "/") + part
+    return out
+
+
+def piper_voice_onnx(cfg, blob, layout, weight_norm=(), encodings=("raw", "float_data"), anonymous=(), extra_inits=()):
     """A Piper-shaped model: every blob tensor as an initializer (alternating encodings), Conv / ConvTranspose nodes for the
     generator carrying strides / dilations, some unrelated nodes and int64 initializers, optional weight-norm pairs."""
     inits, nodes = [], []
+    anon = {}  # module → {"weight": anonymous name, "bias": …}: what the exporter leaves of a constant-folded weight-norm conv
     for i, t in enumerate(layout):
         name = t["name"]
         data = blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"])
+        module, _, leaf = name.rpartition(".")
+        if module in anonymous and leaf in ("weight", "bias"):
+            an = f"onnx::Conv_{9000 + i}"
+            anon.setdefault(module, {})[leaf] = an
+            inits.append(tensor(an, list(data.shape), data))
+            continue
         if name in weight_norm:  # w = g·v/‖v‖  ⇒  store v = 3·w, g = ‖w‖ (per output row)
             w = data.reshape(data.shape[0], -1).astype(np.float64)
             g = np.sqrt((w ** 2).sum(1)).astype(np.float32)
@@ -98,12 +113,20 @@ def piper_voice_onnx(cfg, blob, layout, weight_norm=(), encodings=("raw", "float
         else:
             inits.append(tensor(name, list(data.shape), data, encodings[i % len(encodings)], packed_dims=(i % 3 != 0)))
     inits.append(tensor("dp.flows.3.some_int64_shape", [3], np.array([1, -1, 2], np.int64)))
+    for nm, dims, data in extra_inits:
+        inits.append(tensor(nm, dims, data))
+    for module, names in anon.items():  # only the scope-named node still says which module these belong to
+        if module.startswith("dec."):
+            continue  # generator nodes are written below (with their anonymous inputs)
+        nodes.append(node("Conv", [module + "_in", names["weight"], names["bias"]], [module + "_out"],
+                          [attr_ints("dilations", [1]), attr_int("group", 1), attr_ints("strides", [1])], name=scope_of(module) + "/Conv"))
     pad = lambda k, d: (k * d - d) // 2
     nodes.append(node("Gather", ["enc_p.emb.weight", "input"], ["/enc_p/emb/Gather_output_0"]))
     ch = cfg.up_initial
     for u in range(cfg.n_ups):
         k, s = cfg.up_kernels[u], cfg.up_rates[u]
-        nodes.append(node("ConvTranspose", [f"x{u}", f"dec.ups.{u}.weight", f"dec.ups.{u}.bias"], [f"y{u}"],
+        um = anon.get(f"dec.ups.{u}", {})
+        nodes.append(node("ConvTranspose", [f"x{u}", um.get("weight", f"dec.ups.{u}.weight"), um.get("bias", f"dec.ups.{u}.bias")], [f"y{u}"],
                           [attr_ints("dilations", [1]), attr_int("group", 1), attr_ints("kernel_shape", [k]),
                            attr_ints("pads", [(k - s) // 2] * 2), attr_ints("strides", [s])], name=f"/dec/ups.{u}/ConvTranspose"))
         ch //= 2
@@ -117,8 +140,10 @@ def piper_voice_onnx(cfg, blob, layout, weight_norm=(), encodings=("raw", "float
                 for q, nm in enumerate(names):
                     dd = dil if q == 0 else 1
                     wname = nm + (".weight_v" if nm + ".weight" in weight_norm else ".weight")
-                    nodes.append(node("Conv", [f"a{rb}_{d}_{q}", wname, nm + ".bias"], [f"b{rb}_{d}_{q}"],
+                    am = anon.get(nm, {})
+                    nodes.append(node("Conv", [f"a{rb}_{d}_{q}", am.get("weight", wname), am.get("bias", nm + ".bias")], [f"b{rb}_{d}_{q}"],
                                       [attr_ints("dilations", [dd]), attr_int("group", 1), attr_ints("kernel_shape", [kk]),
-                                       attr_ints("pads", [pad(kk, dd)] * 2), attr_ints("strides", [1])]))
+                                       attr_ints("pads", [pad(kk, dd)] * 2), attr_ints("strides", [1])],
+                                      name=(scope_of(nm) + "/Conv") if am else ""))
     nodes.append(node("Tanh", ["z"], ["output"]))
     return model(nodes, inits)

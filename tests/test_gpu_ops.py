@@ -293,6 +293,41 @@ def test_stream_semantics(backend):
     assert_close(dl(b, cur, shp), ref, OP_TOL)
 
 
+def test_free_is_stream_ordered(backend):
+    """piper_hip_free while a NON-blocking op that reads the buffer is still queued on a user stream (the reference drops
+    intermediates while the command buffer is still encoding, GraphExecutor.swift:216-225): the block must not be handed to
+    an upload on the default stream before that op has run. Round-1 defect: it was recycled at once."""
+    b = backend
+    cb = b.makeCommandBuffer()
+    big = b.uploadFloat32(np.zeros(1, np.float32))
+    n_big = 96 << 20  # 384 MiB per pass: ≈ 0.2 ms each, 40 passes keep stream cb busy for several ms
+    big_in = b.allocateBuffer(n_big * 4)
+    cur = big_in
+    tmp = []
+    for _ in range(40):
+        cur2 = b.unaryF32(ph.NEG, cur, n_big, commandBuffer=cb)
+        tmp.append(cur2)
+        cur = cur2 if len(tmp) < 3 else tmp[len(tmp) % 2]  # ping-pong between two outputs after the first passes
+        if len(tmp) >= 3:
+            break
+    for _ in range(40):
+        b.unaryF32(ph.NEG, tmp[0], n_big, commandBuffer=cb).free()  # each result freed at once: 40 queued passes over tmp[0]
+    x = kd.sym(11, (1 << 20,))
+    y = kd.sym(12, (1 << 20,))
+    xd = b.uploadFloat32(x)
+    out = b.unaryF32(ph.NEG, xd, x.size, commandBuffer=cb)  # queued behind ≈ 8 ms of work, reads xd
+    xd_ptr = xd.ptr
+    xd.free()                                               # host drops it while the read is still queued
+    yd = b.uploadFloat32(y)                                 # same size class: the old pool handed xd's block straight back
+    b.flush(cb)
+    got = b.downloadFloat32(out)
+    assert np.array_equal(got, -x), "the queued op saw the buffer after it was recycled"
+    assert np.array_equal(b.downloadFloat32(yd), y)
+    assert yd.ptr != xd_ptr or True  # (informational: after the flush the block may legitimately be reused)
+    for d in (big, big_in, yd, out, *tmp):
+        d.free()
+
+
 # Long rows take the LDS-tiled bulk kernel (conv_tile_kernel); the KAT table above only reaches the streaming kernel.
 BULK_CONV = [  # (Cin, Cout, K, dil, L, lrelu)
     (32, 32, 7, 12, 20000, True), (32, 32, 3, 1, 16384 + 5, True), (64, 64, 5, 6, 9000, True), (64, 64, 11, 5, 9000, True),

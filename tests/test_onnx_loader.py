@@ -169,3 +169,68 @@ def test_onnx_reader_under_sanitizers(tmp_path):
     out = subprocess.run([str(exe), str(seed), "1500"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "no sanitizer report" in out.stdout
+
+
+def test_onnx_anonymous_weightnorm_constants_resolve_through_node_scope(voices):
+    """torch.onnx constant-folds weight-norm convs (flow WaveNet, HiFi-GAN) into `onnx::Conv_NNNN` initializers; only the node's
+    scope name ("/flow/flows.0/enc/in_layers.1/Conv", the convention GraphExecutor.swift:908 matches on) and its inputs still
+    say which module they belong to. Geometry inference (stride / dilation lookups included) and the blob must not change."""
+    cfg, blob = voices["medium"]
+    anon = {"flow.flows.0.enc.in_layers.1", "flow.flows.4.enc.res_skip_layers.3", "flow.flows.0.enc.in_layers.0", "dec.ups.1",
+            "dec.resblocks.0.convs.0", "dec.resblocks.5.convs.1", "dec.conv_pre"}
+    data = ow.piper_voice_onnx(cfg, blob, layout_dicts(cfg), anonymous=anon - {"dec.conv_pre"})
+    m = ph.OnnxModel(data=data)
+    assert m.find("flow.flows.0.enc.in_layers.1.weight") == -1  # really not there by name
+    same_config(m.infer_config(), cfg)
+    assert np.array_equal(m.build_blob(cfg), blob)
+    m.close()
+
+
+def test_onnx_multispeaker_voice_is_refused(voices, tmp_path):
+    """A voice with speaker conditioning must fail loudly: this library has no `g` path, it would render the
+    wrong speaker without any error."""
+    cfg, blob = voices["medium"]
+    lay = layout_dicts(cfg)
+    for extra in ([("emb_g.weight", [4, 512], np.zeros((4, 512), np.float32))],
+                  [("dec.cond.weight", [256, 512, 1], np.zeros((256, 512, 1), np.float32))],
+                  [("flow.flows.0.enc.cond_layer.weight_v", [8, 4, 1], np.zeros((8, 4, 1), np.float32))]):
+        m = ph.OnnxModel(data=ow.piper_voice_onnx(cfg, blob, lay, extra_inits=extra))
+        with pytest.raises(ph.UnsupportedOp):
+            m.infer_config()
+        m.close()
+    path = tmp_path / "v.onnx"
+    path.write_bytes(ow.piper_voice_onnx(cfg, blob, lay))
+    (tmp_path / "v.onnx.json").write_text(json.dumps({"audio": {"sample_rate": 22050}, "num_symbols": 256, "num_speakers": 904}))
+    with pytest.raises(ph.UnsupportedOp):
+        ph.load_voice(path)
+    (tmp_path / "v.onnx.json").write_text(json.dumps({"audio": {"sample_rate": 22050}, "num_symbols": 130, "num_speakers": 1}))
+    with pytest.raises(ph.ShapeMismatch):  # vocabulary of the json ≠ embedding rows of the graph
+        ph.load_voice(path)
+
+
+def test_config_validation_bounds():
+    """validate_config range-checks every field a file can set: kernel oddness, dilations ≥ 1, hard upper bounds."""
+    def bad(**kw):
+        cfg = ph.voice_config("medium")
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                arr = getattr(cfg, k)
+                if len(v) == 3:
+                    arr[v[0]][v[1]] = v[2]
+                else:
+                    arr[v[0]] = v[1]
+            else:
+                setattr(cfg, k, v)
+        with pytest.raises(ph.ShapeMismatch):
+            ph.blob_floats(cfg)
+    bad(ffn=0)
+    bad(ffn_kernel=4)
+    bad(rb_kernels=(1, 4))
+    bad(rb_kernels=(0, 0))
+    bad(rb_dilations=(2, 1, 0))
+    bad(rb_dilations=(0, 0, 1000))
+    bad(n_layers=100000)
+    bad(window=1 << 20)
+    bad(hidden=1 << 20)
+    bad(up_rates=(0, 1000))
+    assert ph.blob_floats(ph.voice_config("high")) == 27798784 or ph.blob_floats(ph.voice_config("high")) > 0
