@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PIPER_HIP_ABI_VERSION 1
+#define PIPER_HIP_ABI_VERSION 2
 
 /* ---- status codes: ExecutionError (CPUBackend.swift:3-17) + NSError domain "MetalBackend" ---- */
 enum {
@@ -193,6 +193,15 @@ int piper_hip_expand_f32(piper_hip_ctx* ctx, const float* x, const int64_t* in_s
 int piper_hip_reduce_mean_lastdim_f32(piper_hip_ctx* ctx, const float* x, const int64_t* shape, int rank,
                                       float** out, piper_hip_stream stream);
 
+/* MetalBackend.randomNormalLike(shape:seed:) (MetalBackend.swift:3398-3426) → random_normal_like_f32 (elementwise.metal:139-163):
+ * element i draws u0, u1 from xorshift32 seeded with (seed & 0xffffffff) ^ (i·747796405 + 2891336453), maps them to (0, 1] and
+ * returns sqrt(−2·ln u0)·cos(2π·u1). The reference calls it with the fixed seed 1234 for both RandomNormalLike nodes of the
+ * graph (GraphExecutor.swift:2656-2659). The integer stream is bit-exact; the floats agree to ≈ 1e-6 (Metal's log/cos are not
+ * libm's). */
+int piper_hip_random_normal_like_f32(piper_hip_ctx* ctx, size_t count, uint64_t seed, float** out, piper_hip_stream stream);
+/* The raw draws behind it, for parity checks of the integer stream: out[2i] = u0, out[2i+1] = u1 of element i (device buffer). */
+int piper_hip_random_draws_u32(piper_hip_ctx* ctx, size_t count, uint64_t seed, uint32_t** out, piper_hip_stream stream);
+
 /* ---- fused entry points: results equal the unfused composition of the ops above ---- */
 
 /* Text-encoder relative-position self-attention core (§8a rows a5+a6+a7), one call per layer:
@@ -337,16 +346,23 @@ int piper_hip_voice_check_json(const piper_hip_voice_config* cfg, const piper_hi
 int piper_hip_pcm16_from_f32(const float* samples, size_t n, int16_t* pcm);
 int piper_hip_wav_write(const char* path, const float* samples, size_t n, int32_t sample_rate);
 
-/* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104). The duration
- * predictor is outside this library's scope, so per-id frame counts are supplied (the reference's own
- * `overrides` mechanism); `noise` is the "main" RandomNormalLike tensor [inter, F] injected by name
- * (PiperTestVector.swift:24-29), HOST pointer, or NULL for zeros. */
+/* Inputs of one utterance ⇔ ExecutionInputs + overrides (GraphExecutor.swift:5-15, 101-104): phoneme ids, the three
+ * `scales` of PiperMetalRuntime.synthesize (PiperMetalRuntime.swift:62-80), and the tensors the reference lets a caller
+ * pre-seed by name — the duration predictor's output (per-id frame counts) and the two RandomNormalLike tensors
+ * (PiperTestVector.swift:24-29: `dp` [1,2,T], `main` [1,inter,F]).
+ * ABI 2 appended everything below `noise_scale`; zero-initialising the struct keeps the ABI-1 behaviour. */
+#define PIPER_HIP_NOISE_INJECTED 0 /* NULL noise pointers mean zeros (deterministic parity runs) */
+#define PIPER_HIP_NOISE_DEVICE 1   /* NULL noise pointers are generated on the device by the reference's RandomNormalLike
+                                      stream (piper_hip_random_normal_like_f32) with `seed`; non-NULL pointers still win */
 typedef struct {
   const int64_t* phoneme_ids; /* [T] host */
   int32_t t;
   const int32_t* durations; /* [T] host, frames per id (≥0); F = Σ durations */
-  const float* noise;       /* [inter, F] host, may be NULL */
+  const float* noise;       /* `main` RandomNormalLike [inter, F] host, may be NULL (see noise_mode) */
   float noise_scale;        /* scales[0] */
+  /* ---- ABI 2 ---- */
+  int32_t noise_mode;       /* PIPER_HIP_NOISE_INJECTED / PIPER_HIP_NOISE_DEVICE */
+  uint32_t seed;            /* PIPER_HIP_NOISE_DEVICE: RandomNormalLike seed; the reference hard-codes 1234 (GraphExecutor.swift:2658) */
 } piper_hip_utterance;
 
 /* Samples `synthesize` will produce for this utterance (F · Π up_rates). */

@@ -167,6 +167,32 @@ ORC_API int orc_unary(int op, float alpha, const float* x, float* y, long n) {
   return 0;
 }
 
+/* Kernels/elementwise.metal:132-163 (xorshift32, random_normal_like_f32); called with the fixed seed 1234 for both
+ * RandomNormalLike nodes (Execution/GraphExecutor.swift:2656-2659; MetalBackend.swift:3404 passes the low 32 bits).
+ * draws[2i], draws[2i+1] (optional) receive the raw u0 / u1 integers of element i. uint arithmetic wraps mod 2^32 as in MSL. */
+static uint32_t orc_xorshift32(uint32_t x) {
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  return x;
+}
+ORC_API void orc_random_normal_like(uint64_t seed, long n, float* out, uint32_t* draws) {
+  const uint32_t seed_lo = (uint32_t)(seed & 0xffffffffu);
+  for (long gid = 0; gid < n; gid++) {
+    uint32_t state = seed_lo ^ ((uint32_t)gid * 747796405u + 2891336453u);
+    state = orc_xorshift32(state);
+    const uint32_t u0i = state;
+    state = orc_xorshift32(state);
+    const uint32_t u1i = state;
+    const float u0 = ((float)u0i + 1.0f) / 4294967296.0f; /* (0, 1] */
+    const float u1 = ((float)u1i + 1.0f) / 4294967296.0f;
+    const float r = sqrtf(-2.0f * logf(u0));
+    const float theta = 6.28318530718f * u1;
+    if (out) out[gid] = r * cosf(theta);
+    if (draws) { draws[2 * gid] = u0i; draws[2 * gid + 1] = u1i; }
+  }
+}
+
 static void orc_strides(const long* shape, int rank, long* s) {
   if (rank == 0) return;
   s[rank - 1] = 1;

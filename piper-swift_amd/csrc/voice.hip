@@ -21,6 +21,7 @@
 #include "conv.h"
 #include "conv_bf16.h"
 #include "conv_win.h"
+#include "rng.h"
 
 namespace ph {
 int validate_config(const piper_hip_voice_config* c);
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict
 // gather: frame f copies phoneme t(f); bit-identical to the matmul (every other product is an exact ±0 add).
 __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __restrict__ stats, const int32_t* __restrict__ frame2id,
                                                               const float* __restrict__ noise, float* __restrict__ zp, float* __restrict__ zp_tap,
-                                                              int I, int T, int F, const float* __restrict__ noise_scale_dev) {
+                                                              int I, int T, int F, const float* __restrict__ noise_scale_dev,
+                                                              const unsigned* __restrict__ rng_dev) {
   const int nb = blockIdx.y;  // batch item
   stats += (int64_t)nb * 2 * I * T;
   frame2id += (int64_t)nb * F;
@@ -63,13 +65,17 @@ __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __res
   zp += (int64_t)nb * I * F;
   zp_tap += (int64_t)nb * I * F;
   const float noise_scale = noise_scale_dev[nb];  // per-utterance scalar lives in device memory so a replayed graph sees it
+  // RandomNormalLike on the device (random_normal_like_f32, elementwise.metal:139-163): element index = flat index of the
+  // item's [1, I, F] tensor; rng_dev[2nb] = generate?, rng_dev[2nb+1] = seed. Otherwise the injected tensor is read.
+  const bool gen = rng_dev[2 * nb] != 0u;
+  const unsigned seed = rng_dev[2 * nb + 1];
   const int64_t total = (int64_t)I * F;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int c = (int)(i / F), f = (int)(i - (int64_t)c * F);
     const int t = frame2id[f];
     const float m = stats[(int64_t)c * T + t];
     const float lg = stats[(int64_t)(I + c) * T + t];
-    const float nz = noise[i];
+    const float nz = gen ? rnl_normal(seed, (unsigned)i) : noise[i];
     const float r = m + (nz * expf(lg)) * noise_scale;
     zp[i] = r;      // updated in place by the flow couplings
     zp_tap[i] = r;  // pristine copy for the "z_p" debug tap
@@ -149,8 +155,10 @@ struct Slot {
   int64_t* ids = nullptr;
   int32_t* frame2id = nullptr;
   float* noise = nullptr;
-  float* noise_scale = nullptr;  // [1] device
+  float* noise_scale = nullptr;  // [NB] device
+  unsigned* rng = nullptr;       // [NB][2] device: {generate noise on the device?, seed}
   std::vector<float> h_noise_scale;
+  std::vector<unsigned> h_rng;
   float* audio = nullptr;
   int64_t n_samples = 0;
   std::vector<Step> steps;
@@ -821,6 +829,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   s.frame2id = (int32_t*)ar.raw(B * F * sizeof(int32_t));
   s.noise = ar.f32(B * I * F);
   s.noise_scale = ar.f32(B);
+  s.rng = (unsigned*)ar.raw(B * 2 * sizeof(unsigned));
   // ---------------- text encoder
   float* x = ar.f32(B * (size_t)H * T);
   float* x1 = ar.f32(B * (size_t)H * T);
@@ -906,9 +915,10 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     const int32_t* f2i = s.frame2id;
     const float* nz = s.noise;
     const float* nsd = s.noise_scale;
+    const unsigned* rngd = s.rng;
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
-      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid, NB), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd);
+      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid, NB), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd, rngd);
       return PIPER_HIP_OK;
     };
     // path expansion counted as the reference's two MatMuls mm(1,F,192,T)
@@ -1380,8 +1390,13 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
     s.h_cap_f = (size_t)F * n;
   }
   s.h_noise_scale.resize(n);
+  s.h_rng.resize(2 * (size_t)n);
   for (int b = 0; b < n; b++) {
     const piper_hip_utterance* u = &utts[b];
+    if (u->noise_mode != PIPER_HIP_NOISE_INJECTED && u->noise_mode != PIPER_HIP_NOISE_DEVICE)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: unknown noise_mode %d", b, u->noise_mode);
+    s.h_rng[2 * b] = (!u->noise && u->noise_mode == PIPER_HIP_NOISE_DEVICE) ? 1u : 0u;
+    s.h_rng[2 * b + 1] = u->seed;
     memcpy(s.h_ids + (size_t)b * T, u->phoneme_ids, (size_t)T * sizeof(int64_t));
     int f = 0;  // generate_path: frame f belongs to the phoneme whose cumulative duration covers it
     for (int t = 0; t < T; t++)
@@ -1390,9 +1405,10 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
     if (u->noise)
       PH_HIP(hipMemcpyAsync(s.noise + (size_t)b * I * F, u->noise, (size_t)I * F * sizeof(float), hipMemcpyHostToDevice, s.stream),
              PIPER_HIP_ERR_LAUNCH);
-    else
+    else if (!s.h_rng[2 * b])
       PH_HIP(hipMemsetAsync(s.noise + (size_t)b * I * F, 0, (size_t)I * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
   }
+  PH_HIP(hipMemcpyAsync(s.rng, s.h_rng.data(), 2 * (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.noise_scale, s.h_noise_scale.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * n * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * n * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);

@@ -104,7 +104,10 @@ class PiperJsonInfo(C.Structure):
 
 class Utterance(C.Structure):
     _fields_ = [("phoneme_ids", c_i64p), ("t", C.c_int32), ("durations", c_i32p), ("noise", c_f32p),
-                ("noise_scale", C.c_float)]
+                ("noise_scale", C.c_float), ("noise_mode", C.c_int32), ("seed", C.c_uint32)]
+
+
+NOISE_MODES = {"injected": 0, "device": 1}
 
 
 class KernelStat(C.Structure):
@@ -150,6 +153,8 @@ _PROTOS = {
     "piper_hip_split2_axis1_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int64, C.POINTER(c_vp), C.POINTER(c_vp), c_vp]),
     "piper_hip_expand_f32": (C.c_int, [c_vp, c_vp, c_i64p, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
     "piper_hip_reduce_mean_lastdim_f32": (C.c_int, [c_vp, c_vp, c_i64p, C.c_int, C.POINTER(c_vp), c_vp]),
+    "piper_hip_random_normal_like_f32": (C.c_int, [c_vp, C.c_size_t, C.c_uint64, C.POINTER(c_vp), c_vp]),
+    "piper_hip_random_draws_u32": (C.c_int, [c_vp, C.c_size_t, C.c_uint64, C.POINTER(c_vp), c_vp]),
     "piper_hip_rel_attention_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64,
                                               C.c_int64, C.c_int64, C.POINTER(c_vp), c_vp]),
     "piper_hip_add_layernorm_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_float,
@@ -500,6 +505,22 @@ class HipBackend:
                                                           commandBuffer))
         return self._out(p, list(shape[:-1]))
 
+    def randomNormalLike(self, shape, seed=1234, commandBuffer=None):
+        """MetalBackend.randomNormalLike(shape:seed:) — device buffer of prod(shape) floats."""
+        n = int(np.prod(shape)) if len(shape) else 1
+        p = c_vp()
+        _check(self.lib.piper_hip_random_normal_like_f32(self.ctx, n, int(seed), C.byref(p), commandBuffer))
+        return DeviceBuffer(self, p.value, n)
+
+    def randomDraws(self, count, seed=1234):
+        """The raw (u0, u1) 32-bit draws per element, as a host uint32 array [count, 2]."""
+        p = c_vp()
+        _check(self.lib.piper_hip_random_draws_u32(self.ctx, int(count), int(seed), C.byref(p), None))
+        out = np.empty(2 * int(count), np.float32)
+        _check(self.lib.piper_hip_download_f32(self.ctx, p, out.ctypes.data_as(c_f32p), 2 * int(count)))
+        _check(self.lib.piper_hip_free(self.ctx, p))
+        return out.view(np.uint32).reshape(-1, 2)
+
     # -- fused
     def relAttentionF32(self, q, k, v, embRelK, embRelV, n, heads, headDim, t, window, commandBuffer=None):
         p = c_vp()
@@ -673,12 +694,13 @@ class HipRuntime:
         _check(self.lib.piper_hip_voice_set_precision(self.voice, int(code)))
         self._keep.clear()  # prepared slots are dropped by the library
 
-    def _utt(self, ids, durations, noise, noise_scale):
+    def _utt(self, ids, durations, noise, noise_scale, noise_mode="injected", seed=1234):
         ids = np.ascontiguousarray(ids, np.int64)
         dur = np.ascontiguousarray(durations, np.int32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
         u = Utterance(ids.ctypes.data_as(c_i64p), len(ids), dur.ctypes.data_as(c_i32p),
-                      None if nz is None else nz.ctypes.data_as(c_f32p), float(noise_scale))
+                      None if nz is None else nz.ctypes.data_as(c_f32p), float(noise_scale),
+                      NOISE_MODES.get(noise_mode, noise_mode), int(seed) & 0xFFFFFFFF)
         return u, (ids, dur, nz)
 
     def num_samples(self, ids, durations):
@@ -693,8 +715,8 @@ class HipRuntime:
         _check(self.lib.piper_hip_voice_synthesize(self.voice, C.byref(u), out.ctypes.data_as(c_f32p), n, C.byref(got)))
         return out[:got.value]
 
-    def prepare(self, slot, phonemeIDs, durations, noise=None, noiseScale=0.667):
-        u, k = self._utt(phonemeIDs, durations, noise, noiseScale)
+    def prepare(self, slot, phonemeIDs, durations, noise=None, noiseScale=0.667, noise_mode="injected", seed=1234):
+        u, k = self._utt(phonemeIDs, durations, noise, noiseScale, noise_mode, seed)
         self._keep[slot] = (k, int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u))))
         rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
         if rc < 0:

@@ -118,6 +118,13 @@ def binary(op, a, b):
     return out
 
 
+def random_normal_like(n, seed=1234, draws=False):
+    out = np.zeros(n, np.float32)
+    raw = np.zeros(2 * n, np.uint32)
+    lib().orc_random_normal_like(C.c_uint64(seed), C.c_long(n), _f(out), raw.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return (out, raw.reshape(-1, 2)) if draws else out
+
+
 def pad(x, pads, value=0.0):
     x = _c(x)
     r = x.ndim
