@@ -10,6 +10,7 @@
 // A block owns R query rows of one head; the R×T score strip lives in LDS (T ≤ 4096: the reference's own
 // --max-phonemes cap, PiperCLI.swift:394).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -223,13 +224,222 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
   PH_STAMP(7);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA formulation (exact fp32, v_mfma_f32_16x16x4_f32), operands straight from global memory into fragments.
+//
+// A block owns RV query rows of one head (RV = 16, or 8 valid rows of a 16-row tile when the score strip of 16 rows would
+// not fit the LDS) and 8 waves:
+//   1. scores: wave w takes key tiles w, w+8, … (16 keys each): S[i][j] = Σ_c (q[c][i]/√d)·k[c][j] — A = the q strip
+//      (d/4 fragments per lane, loaded once), B = k read in place ([c][j] is already the B layout: 16 consecutive keys of 4
+//      consecutive channels per instruction); the tile after the last is the relative-key logits q·E_kᵀ (B = E_k). No K tile
+//      is ever staged: nothing is shared between the waves of a block, so LDS would only add a round trip.
+//   2. softmax over the strip in LDS (rel→abs skew = index arithmetic on the 16×(2w+1) logits), one wave per row.
+//   3. out[c][i] = Σ_j v[c][j]·P[i][j] + Σ_m E_v[m][c]·P[i][i+m−w]: wave w takes channel tile w (16 channels), A = v read in
+//      place, B = Pᵀ from LDS; the relative-value term is ⌈(2w+1)/4⌉ more steps on the same accumulator (abs→rel skew again
+//      as index arithmetic).
+// A first MFMA attempt in round 1 staged K and V through LDS tiles and was slower than the scalar kernel below; the cost
+// was the staging chain, not the arithmetic. `len_ptr` (optional) gives the true length of each batch item inside a
+// bucketed schedule: keys ≥ len are excluded exactly (they are not part of the softmax), rows ≥ len are not computed.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAttWaves = 8;
+
+template <int D, int RV>
+__global__ __launch_bounds__(64 * kAttWaves) void rel_attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                           const float* __restrict__ v, const float* __restrict__ ek,
+                                                                           const float* __restrict__ ev, float* __restrict__ out, int T,
+                                                                           int w, int64_t in_batch_stride, int64_t out_batch_stride,
+                                                                           const int* __restrict__ len_ptr, int Tp) {
+  constexpr int NS = D / 4;   // contraction steps over the head dim
+  constexpr int NCT = D / 16; // channel tiles of the output
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sc = smem;            // [RV][Tp] scores → probabilities
+  float* qe = smem + RV * Tp;  // [16][17] relative-key logits of the strip
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.x * RV, h = blockIdx.y, n = blockIdx.z;
+  const int Tv = len_ptr ? min(len_ptr[n], T) : T;  // block-uniform true length
+  if (i0 >= Tv) return;
+  const int W = 2 * w + 1;
+  const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+  const float* kb = k + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+  const float* vb = v + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+  const float scale = sqrtf((float)D);
+  const int nkt = (Tv + 15) >> 4;  // key tiles; tile index nkt is the relative-key tile
+
+  // ---- 1. scores
+  {
+    float qa[NS];
+    const bool row_ok = r16 < RV && i0 + r16 < Tv;
+    const int qi = min(i0 + r16, Tv - 1);
+#pragma unroll
+    for (int s = 0; s < NS; s++) qa[s] = qb[(int64_t)(4 * s + kq) * T + qi];
+#pragma unroll
+    for (int s = 0; s < NS; s++) qa[s] = row_ok ? qa[s] / scale : 0.0f;  // Div of the graph: query / sqrt(k_channels)
+    float b0[NS], b1[NS];
+    auto load_tile = [&](float (&b)[NS], int jt) {
+      if (jt < nkt) {
+        const int j = jt * 16 + r16;
+        const int jc = min(j, Tv - 1);
+#pragma unroll
+        for (int s = 0; s < NS; s++) b[s] = kb[(int64_t)(4 * s + kq) * T + jc];
+      } else {  // E_k[m][c] as B[k = c][n = m]
+        const int mc = min(r16, W - 1);
+#pragma unroll
+        for (int s = 0; s < NS; s++) b[s] = ek[mc * D + 4 * s + kq];
+      }
+    };
+    auto compute_tile = [&](const float (&b)[NS], int jt) {
+      const bool col_ok = jt < nkt ? (jt * 16 + r16 < Tv) : (r16 < W);
+      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], col_ok ? b[s] : 0.0f, acc, 0, 0, 0);
+      // D: row = 4·kq + r (query), col = r16 (key / relative position)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 4 * kq + r;
+        if (row < RV) {
+          if (jt < nkt) sc[row * Tp + jt * 16 + r16] = acc[r];
+          else qe[row * 17 + r16] = acc[r];
+        }
+      }
+    };
+    // wave-uniform tile loop with the next tile's fragments in flight under the current tile's MFMAs
+    int jt = wave;
+    if (jt <= nkt) load_tile(b0, jt);
+    while (jt <= nkt) {
+      const int jn = jt + kAttWaves;
+      if (jn <= nkt) load_tile(b1, jn);
+      compute_tile(b0, jt);
+      jt = jn;
+      if (jt > nkt) break;
+      const int jn2 = jt + kAttWaves;
+      if (jn2 <= nkt) load_tile(b0, jn2);
+      compute_tile(b1, jt);
+      jt = jn2;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. softmax (softmax.metal:13-41: max, exp and sum, multiply by 1/sum), relative-key logits added on the way in
+  for (int r = wave; r < RV; r += kAttWaves) {
+    const int ia = i0 + r;
+    if (ia >= Tv) break;  // wave-uniform
+    float* row = sc + r * Tp;
+    const float* qr = qe + r * 17;
+    float m = -INFINITY;
+    for (int j = lane; j < Tv; j += 64) {
+      const int delta = j - ia;
+      float sv = row[j];
+      if (delta >= -w && delta <= w) sv += qr[delta + w];
+      row[j] = sv;
+      m = fmaxf(m, sv);
+    }
+    m = wave_max(m);
+    float sum = 0.0f;
+    for (int j = lane; j < Tv; j += 64) {
+      const float e = expf(row[j] - m);
+      row[j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tv; j += 64) row[j] *= inv;
+  }
+  __syncthreads();
+
+  // ---- 3. P·V + relative-value term
+  if (wave < NCT) {
+    const int c0 = wave * 16;
+    const float* vrow = vb + (int64_t)(c0 + r16) * T;        // A[m = channel][k = key]
+    const bool pi_ok = r16 < RV && i0 + r16 < Tv;            // B[k = key][n = query row]
+    const float* prow = sc + min(r16, RV - 1) * Tp;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int CH = 8;  // steps per prefetch chunk
+    const int nsteps = (Tv + 3) >> 2;
+    float a0[CH], a1[CH];
+    auto load_a = [&](float (&a)[CH], int s0) {
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int j = 4 * (s0 + u) + kq;
+        a[u] = vrow[min(j, Tv - 1)];
+      }
+    };
+    auto run = [&](const float (&a)[CH], int s0) {
+      float b[CH];
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int j = 4 * (s0 + u) + kq;
+        b[u] = prow[min(j, Tv - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int j = 4 * (s0 + u) + kq;
+        const bool ok = j < Tv;  // also false for the steps past nsteps of the last chunk
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a[u] : 0.0f, (ok && pi_ok) ? b[u] : 0.0f, acc, 0, 0, 0);
+      }
+    };
+    load_a(a0, 0);
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * CH) {
+      if (s0 + CH < nsteps) load_a(a1, s0 + CH);
+      run(a0, s0);
+      if (s0 + CH >= nsteps) break;
+      if (s0 + 2 * CH < nsteps) load_a(a0, s0 + 2 * CH);
+      run(a1, s0 + CH);
+    }
+    // relative values: A = E_v[m][c], B = P[i][i + m − w] (abs→rel skew as an index)
+    const int ia = i0 + r16;
+    for (int s = 0; 4 * s < W; s++) {
+      const int mrel = 4 * s + kq;
+      const bool mok = mrel < W;
+      const float a = ev[min(mrel, W - 1) * D + c0 + r16];
+      const int j = ia + mrel - w;
+      const bool jok = mok && pi_ok && j >= 0 && j < Tv;
+      const float b = prow[jok ? j : 0];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? a : 0.0f, jok ? b : 0.0f, acc, 0, 0, 0);
+    }
+    // D: row = channel 4·kq + r, col = query row r16
+    float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * D * T;
+    if (pi_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) ob[(int64_t)(c0 + 4 * kq + r) * T + i0 + r16] = acc[r];
+    }
+  }
+}
+
+template <int D, int RV>
+int launch_att_mfma(hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, float* out, int N, int H,
+                    int T, int w, int64_t in_bs, int64_t out_bs, const int* len_ptr) {
+  const int Tp = ((T + 31) / 32) * 32 + 2;  // ≡ 2 mod 32: the Pᵀ fragment reads (16 rows × 2 keys per half wave) hit 32 distinct banks
+  const size_t lds = ((size_t)RV * Tp + 16 * 17) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  static bool raised[ph::kMaxDevices] = {};
+  if (lds > 64 * 1024 && ph::lds_optin_needed(raised))
+    (void)hipFuncSetAttribute((const void*)rel_attention_mfma_kernel<D, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid((unsigned)ph::ceil_div(T, RV), (unsigned)H, (unsigned)N);
+  hipLaunchKernelGGL((rel_attention_mfma_kernel<D, RV>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp);
+  return 0;
+}
+
 }  // namespace
 
 namespace ph {
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
-                         int64_t out_batch_stride) {
+                         int64_t out_batch_stride, const int* len_ptr) {
   if (N <= 0 || T <= 0) return PIPER_HIP_OK;
+  static const bool no_mfma = getenv("PIPER_HIP_ATT_SCALAR") != nullptr;  // A/B switch: the round-1 scalar kernel
+  if (!no_mfma && d == 96 && w >= 0 && 2 * w + 1 <= 16 && H <= 65535 && N <= 65535 && T <= 4096) {
+    int rc = T <= 2048 ? launch_att_mfma<96, 16>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr)
+                       : launch_att_mfma<96, 8>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr);
+    if (rc == 0) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention (mfma) launch failed: %s", hipGetErrorString(e));
+      return PIPER_HIP_OK;
+    }
+  }
+  if (len_ptr) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: per-item lengths need the MFMA kernel (head_dim 96, window ≤ 7)");
   if (d > kBlock) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: head_dim %d > %d", d, kBlock);
   if (T > 4096) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rel_attention: T=%d exceeds 4096 (reference max-phonemes cap)", T);
   if (H > 65535 || N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "rel_attention: heads/batch too large");
@@ -285,7 +495,7 @@ PH_EXPORT int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, co
   ph::StreamScope ss(ctx, stream);
   const int64_t bs = heads * head_dim * t;
   rc = ph::launch_rel_attention(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, *out, (int)n, (int)heads, (int)head_dim, (int)t,
-                                (int)window, bs, bs);
+                                (int)window, bs, bs, nullptr);
   if (rc) return rc;
   return ss.finish("rel_attention_f32");
 }

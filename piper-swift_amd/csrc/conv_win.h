@@ -26,6 +26,10 @@ struct ConvWinArgs {
   int Lout = 0;                 // GEMM columns (conv: output length; convT: input length)
   int y_len = 0;                // row length of y / res / mrf_*
   int ct_stride = 0, ct_pad = 0;  // ConvTranspose1d: rows (phase ρ, co), K/s taps, output position s·q + ρ
+  // bucketed schedules: true input length of batch item n = len_ptr[n]·len_mul (≤ Lin); positions beyond it read as zero
+  // padding, exactly as if the tensor ended there. null ⇒ Lin.
+  const int* len_ptr = nullptr;
+  int len_mul = 1;
 };
 
 size_t packed_conv_win_floats(int Cout, int Cin, int K);
@@ -43,5 +47,15 @@ int launch_conv_win(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs& a);
 // three short dependent-free ones: the blocks of all convs share the chip, and two launch boundaries disappear.
 constexpr int kWinMulti = 3;
 int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* convs, int count);
+
+// ---- conv_pipe.hip: the same contraction as a persistent, chunk-pipelined kernel (Cin % 32 == 0); its own fragment order
+size_t packed_conv_pipe_floats(int Cout, int Cin, int K);
+size_t packed_convt_pipe_floats(int Cin, int Cout, int K, int stride);
+int pack_conv_weights_pipe(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
+int pack_convt_weights_pipe(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, int pad, float* packed);
+bool conv_pipe_eligible(int Cout, int Cin, int K, int dil, int padL, int Lin, int Lout);
+bool convt_pipe_eligible(int Cin, int Cout, int K, int stride, int pad, int Lin);
+// convs[i].w4 must be the pipe image; same multi-conv contract as launch_conv_win_multi
+int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* convs, int count);
 
 }  // namespace ph

@@ -55,17 +55,21 @@ PH_EXPORT int piper_hip_conv1d_f32(piper_hip_ctx* ctx, const float* x, const int
   static const bool no_win = getenv("PIPER_HIP_NO_WIN") != nullptr;
   if (!no_win && g == 1 && p->stride == 1 && Lout >= 1024 && Cout >= 16 && ((uintptr_t)x & 15) == 0 &&
       conv_win_eligible((int)Cout, (int)Cin, (int)K, p->dilation, p->pad_l, (int)Lin, (int)Lout)) {
-    // long rows: window kernel (input window staged once in LDS)
+    // long rows: the persistent chunk-pipelined kernel when the channel count allows (Cin % 32 == 0), else the one-shot
+    // window kernel (input window staged once in LDS)
+    static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
+    const bool pipe = !no_pipe && conv_pipe_eligible((int)Cout, (int)Cin, (int)K, p->dilation, p->pad_l, (int)Lin, (int)Lout);
     float* packed = nullptr;
-    rc = pool_floats(ctx, packed_conv_win_floats((int)Cout, (int)Cin, (int)K), &packed);
+    rc = pool_floats(ctx, pipe ? packed_conv_pipe_floats((int)Cout, (int)Cin, (int)K) : packed_conv_win_floats((int)Cout, (int)Cin, (int)K), &packed);
     if (rc) return rc;
     defer_free(ctx, packed);
-    pack_conv_weights_win(ss.s, w, (int)Cout, (int)Cin, (int)K, packed);
+    if (pipe) pack_conv_weights_pipe(ss.s, w, (int)Cout, (int)Cin, (int)K, packed);
+    else pack_conv_weights_win(ss.s, w, (int)Cout, (int)Cin, (int)K, packed);
     ConvWinArgs wa;
     wa.x = x; wa.w4 = packed; wa.bias = bias; wa.y = *out;
     wa.N = (int)N; wa.Cin = (int)Cin; wa.Cout = (int)Cout; wa.K = (int)K; wa.dil = p->dilation; wa.padL = p->pad_l;
     wa.Lin = (int)Lin; wa.Lout = (int)Lout; wa.y_len = (int)Lout;
-    rc = launch_conv_win(ctx, ss.s, wa);
+    rc = pipe ? launch_conv_pipe_multi(ctx, ss.s, &wa, 1) : launch_conv_win(ctx, ss.s, wa);
   } else if (Lin >= 1 && conv_mfma_eligible((int)Cout, (int)Cin, (int)K, p->stride, (int)g)) {
     const int tm = conv_pick_tile(ctx, (int)Cout, (int)Lout, (int)N, 0);
     float* packed = nullptr;
@@ -112,16 +116,19 @@ PH_EXPORT int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, 
   static const bool no_win = getenv("PIPER_HIP_NO_WIN") != nullptr;
   if (!no_win && g == 1 && p->dilation == 1 && p->output_padding == 0 && p->pad_l == p->pad_r && Lin >= 256 &&
       ((uintptr_t)x & 15) == 0 && convt_win_eligible((int)Cin, (int)Cout, (int)K, s, p->pad_l, (int)Lin)) {
+    static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
+    const bool pipe = !no_pipe && convt_pipe_eligible((int)Cin, (int)Cout, (int)K, s, p->pad_l, (int)Lin);
     float* packed = nullptr;
-    rc = pool_floats(ctx, packed_convt_win_floats((int)Cin, (int)Cout, (int)K, s), &packed);
+    rc = pool_floats(ctx, pipe ? packed_convt_pipe_floats((int)Cin, (int)Cout, (int)K, s) : packed_convt_win_floats((int)Cin, (int)Cout, (int)K, s), &packed);
     if (rc) return rc;
     defer_free(ctx, packed);
-    pack_convt_weights_win(ss.s, w, (int)Cin, (int)Cout, (int)K, s, p->pad_l, packed);
+    if (pipe) pack_convt_weights_pipe(ss.s, w, (int)Cin, (int)Cout, (int)K, s, p->pad_l, packed);
+    else pack_convt_weights_win(ss.s, w, (int)Cin, (int)Cout, (int)K, s, p->pad_l, packed);
     ConvWinArgs wa;
     wa.x = x; wa.w4 = packed; wa.bias = bias; wa.y = *out;
     wa.N = (int)N; wa.Cin = (int)Cin; wa.Cout = (int)Cout; wa.K = (int)K; wa.Lin = (int)Lin; wa.Lout = (int)Lin; wa.y_len = (int)Lout;
     wa.ct_stride = s; wa.ct_pad = p->pad_l;
-    rc = launch_conv_win(ctx, ss.s, wa);
+    rc = pipe ? launch_conv_pipe_multi(ctx, ss.s, &wa, 1) : launch_conv_win(ctx, ss.s, wa);
   } else if (g == 1 && p->dilation == 1 && Cin >= 2 && Cout * s >= 8 && Lin >= 1) {
     // phase decomposition: output phase (x+padL) mod s is a dense conv with ceil(K/s) taps (no '%' test per tap)
     const int J = (int)((K + s - 1) / s);

@@ -27,7 +27,7 @@ namespace ph {
 int validate_config(const piper_hip_voice_config* c);
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
-                         int64_t out_batch_stride);
+                         int64_t out_batch_stride, const int* len_ptr);
 }  // namespace ph
 
 using namespace ph;
@@ -138,6 +138,7 @@ struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bi
   const float* w = nullptr;
   const float* w16 = nullptr;  // 16-wide fragment image (short-utterance geometry)
   const float* w4 = nullptr;   // conv_win_kernel fragment image (generator convs: long rows)
+  const float* w5 = nullptr;   // conv_pipe_kernel fragment image (chunk-major step order; Cin % 32 == 0)
   const float* bias = nullptr;
   int Cout = 0, Cin = 0, K = 1;
   bool mfma = false;
@@ -267,6 +268,11 @@ ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int C
       float* p4 = pk.take(packed_conv_win_floats(Cout, Cin, K));
       if (!dry) pack_conv_weights_win(pk.s, w, Cout, Cin, K, p4);
       c.w4 = p4;
+      if (Cin % 32 == 0 && K * (Cin / 32) >= 2) {
+        float* p5 = pk.take(packed_conv_pipe_floats(Cout, Cin, K));
+        if (!dry) pack_conv_weights_pipe(pk.s, w, Cout, Cin, K, p5);
+        c.w5 = p5;
+      }
     }
   } else {
     c.w = w;
@@ -344,9 +350,13 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
     const bool ct_win = convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, 4);
     float* p4 = ct_win ? pk.take(packed_convt_win_floats(S.Cin, S.Cout, S.K, S.stride)) : nullptr;
     S.up.w4 = ct_win ? p4 : nullptr;
+    const bool ct_pipe = convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, 4);
+    float* p5 = ct_pipe ? pk.take(packed_convt_pipe_floats(S.Cin, S.Cout, S.K, S.stride)) : nullptr;
+    S.up.w5 = p5;
     if (!dry) {
       snprintf(nm, sizeof nm, "dec.ups.%d", u);
       if (ct_win) pack_convt_weights_win(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, S.pad, p4);
+      if (ct_pipe) pack_convt_weights_pipe(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, S.pad, p5);
       pack_convt_weights(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, p);
       pack_convt_weights(pk.s, tensor(v, std::string(nm) + ".weight"), S.Cin, S.Cout, S.K, S.stride, p16, 16);
       S.up.bias = tensor(v, std::string(nm) + ".bias");
@@ -686,6 +696,11 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   piper_hip_ctx* ctx = v->ctx;
   const size_t B = (size_t)NB;
   if (c.n_rb != kWinMulti) return PIPER_HIP_ERR_UNSUPPORTED;
+  // A/B switches: PIPER_HIP_NO_PIPE=1 keeps round 1's one-tile-per-block window kernel; PIPER_HIP_PIPE_MIN_F (frames × batch)
+  // is the size below which the window kernel's in-block K-split still wins (very short utterances: fewer tiles than CUs)
+  static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
+  static const int pipe_min_f = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_F"); return e ? atoi(e) : 0; }();
+  const bool use_pipe = !no_pipe && (int64_t)NB * F >= pipe_min_f;
   {
     int L = F;
     for (int u = 0; u < c.n_ups; u++) {
@@ -721,13 +736,15 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       st.tag = "conv_mfma";
       st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;
       st.bytes = NB * 4.0 * ((double)S.Cin * L * (cur[1] ? 3 : 1) + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
-      if (S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L)) {
+      const bool ct_pipe = use_pipe && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
+      if (ct_pipe || (S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L))) {
         ConvWinArgs wa;
-        wa.x = cur[0]; wa.x2 = cur[1]; wa.x3 = cur[2]; wa.w4 = S.up.w4; wa.bias = S.up.bias; wa.y = up;
+        wa.x = cur[0]; wa.x2 = cur[1]; wa.x3 = cur[2]; wa.w4 = ct_pipe ? S.up.w5 : S.up.w4; wa.bias = S.up.bias; wa.y = up;
         wa.pro_alpha = 0.1f;
         wa.N = NB; wa.Cin = S.Cin; wa.Cout = S.Cout; wa.K = S.K; wa.Lin = L; wa.Lout = L; wa.y_len = Lo;
         wa.ct_stride = S.stride; wa.ct_pad = S.pad;
-        st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
+        if (ct_pipe) st.run = [ctx, wa](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, &wa, 1); };
+        else st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
       } else {
         ConvArgs a;
         a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
@@ -746,10 +763,13 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
                          const float* const res[kWinMulti], float* const y[kWinMulti], const int dil[kWinMulti]) {
       struct Pack { ConvWinArgs a[kWinMulti]; } pk;
       double fl = 0, by = 0;
+      bool pipe = use_pipe;
+      for (int j = 0; j < kWinMulti; j++)
+        pipe = pipe && ws[j]->w5 && conv_pipe_eligible(ws[j]->Cout, ws[j]->Cin, ws[j]->K, dil[j], (ws[j]->K * dil[j] - dil[j]) / 2, Lo, Lo);
       for (int j = 0; j < kWinMulti; j++) {
         ConvWinArgs& wa = pk.a[j];
         const ConvW& w = *ws[j];
-        wa.x = x[j]; wa.w4 = w.w4; wa.bias = w.bias; wa.res = res[j]; wa.y = y[j];
+        wa.x = x[j]; wa.w4 = pipe ? w.w5 : w.w4; wa.bias = w.bias; wa.res = res[j]; wa.y = y[j];
         wa.pro_alpha = 0.1f;
         wa.N = NB; wa.Cin = w.Cin; wa.Cout = w.Cout; wa.K = w.K; wa.dil = dil[j]; wa.padL = (w.K * dil[j] - dil[j]) / 2;
         wa.Lin = Lo; wa.Lout = Lo; wa.y_len = Lo;
@@ -758,7 +778,8 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       }
       Step st;
       st.name = name;
-      st.run = [ctx, pk](hipStream_t q) { return launch_conv_win_multi(ctx, q, pk.a, kWinMulti); };
+      if (pipe) st.run = [ctx, pk](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, pk.a, kWinMulti); };
+      else st.run = [ctx, pk](hipStream_t q) { return launch_conv_win_multi(ctx, q, pk.a, kWinMulti); };
       st.flops = fl; st.bytes = by;
       st.tag = "conv_mfma";
       s.steps.push_back(std::move(st));
@@ -873,7 +894,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       const int nh = c.n_heads, w = c.window;
       st.run = [=](hipStream_t q) {
         return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
-                                    (int64_t)3 * H * T, (int64_t)H * T);
+                                    (int64_t)3 * H * T, (int64_t)H * T, nullptr);
       };
       // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
       st.flops = NB * 2.0 * nh * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);

@@ -214,6 +214,13 @@ CONV_WIN_CASES = [
     (32, 40, 5, 2, 3, 5, 1300, 1, True),       # ragged Cout, asymmetric pads, L % 4 == 0 but not % 32
     (256, 256, 11, 5, 25, 25, 1344, 1, True),  # high stage 0, widest window (Cin × reach)
     (34, 48, 3, 3, 3, 3, 1028, 1, True),       # odd channel-pair count (17): step padding inside a K range
+    # conv_pipe.hip (persistent, chunk-pipelined; Cin % 32 == 0): blocks that walk several tiles, both ring phases, two column
+    # tiles per wave, a row group with surplus waves, batch > 1
+    (32, 32, 3, 1, 1, 1, 200000, 1, True),     # 1 563 tiles of 128 columns on ≤ 768 resident blocks: 2–3 tiles per block, odd tap count
+    (32, 32, 5, 2, 4, 4, 262148, 1, True),     # NTW = 2 (256-column tiles), L % 256 ≠ 0
+    (64, 64, 3, 2, 2, 2, 70000, 2, False),     # 2×2 waves × 2 column tiles, batch 2, 2 chunks per tile, no bias
+    (64, 96, 3, 2, 2, 2, 3000, 1, True),       # 3 row tiles in row groups of 2: the last group's second wave is surplus
+    (96, 32, 2, 1, 0, 1, 5000, 1, True),       # even tap count (ring phase never flips), 3 chunks, asymmetric pads
 ]
 # (Cin, Cout, K, stride, L, N)
 CONVT_WIN_CASES = [
@@ -221,4 +228,6 @@ CONVT_WIN_CASES = [
     (64, 32, 8, 4, 1024, 2),
     (256, 128, 16, 8, 336, 1),
     (128, 64, 4, 2, 260, 1),
+    (64, 32, 8, 4, 60000, 1),   # conv_pipe: 4 row tiles (one per phase) × 1 875 column tiles: several tiles per block
+    (32, 32, 4, 2, 9000, 2),    # one chunk per tile, 2 phases × 32 rows, batch 2
 ]
