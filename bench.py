@@ -455,6 +455,32 @@ def main():
             out["cpu_baseline"] = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
                                    "cores": cores, "kind": "port",
                                    "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
+            # SURVEY.md §8d fallback (ii): PyTorch-CPU eager fp32 on the same synthetic graph (tests/torch_ref.py, library conv /
+            # matmul kernels) — the closest stand-in for the ORT-CPU baseline the north star names (onnxruntime and a Piper
+            # .onnx are not available offline). Reported beside the naive port, not instead of it.
+            try:
+                import torch
+                import torch_ref
+                torch.set_num_threads(cores)
+                tref = torch_ref.Ref(cfg, blob)
+                with torch.no_grad():
+                    tref.synthesize(ids, dur, noise, 0.667)  # warm-up (thread pool, oneDNN primitive cache)
+                    treps = 5
+                    a = time.perf_counter()
+                    for _ in range(treps):
+                        tref.synthesize(ids, dur, noise, 0.667)
+                    tdt = (time.perf_counter() - a) / treps
+                cpu_model = ""
+                try:
+                    cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+                except Exception:
+                    pass
+                out["cpu_baseline_torch"] = {"value": round(audio_sec / tdt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(tdt * 1e3, 2),
+                                             "cores": cores, "kind": "torch-cpu-eager-fp32", "torch": torch.__version__, "cpu": cpu_model,
+                                             "sample": f"{treps} utterances of the same factor-{args.factor} workload after 1 warm-up (tests/torch_ref.py)"}
+                out["cpu_baseline"]["cpu"] = cpu_model
+            except Exception as e:  # torch missing on the box: say so, do not substitute
+                out["cpu_baseline_torch"] = {"unavailable": repr(e)}
         if batch32 is not None:
             out["batch32"] = batch32
         sys.stdout.flush()

@@ -214,6 +214,16 @@ int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, const float*
                                 const float* emb_rel_k, const float* emb_rel_v, int64_t n, int64_t heads,
                                 int64_t head_dim, int64_t t, int64_t window, float** out, piper_hip_stream stream);
 
+/* The attention block of an encoder layer in ONE launch: out = LN_c(x + conv_o(rel_attention(q, k, v)))·gamma + beta, with
+ * conv_o the k = 1 output projection (w_o [C, C, 1], b_o [C], C = heads·head_dim). Equals rel_attention_f32 → conv1d_f32 →
+ * add_layernorm_f32 (GraphExecutor.swift:1862-1929 + Conv :1739-1810 + Add :741-779 + LayerNorm chain :2071-2125) without the
+ * two intermediate tensors. Covered: head_dim 96, C ≤ 256, window ≤ 7, T ≤ 2048; otherwise PIPER_HIP_ERR_UNSUPPORTED and the
+ * caller composes the three ops. */
+int piper_hip_attention_block_f32(piper_hip_ctx* ctx, const float* q, const float* k, const float* v, const float* emb_rel_k,
+                                  const float* emb_rel_v, const float* w_o, const float* b_o, const float* x, const float* gamma,
+                                  const float* beta, int64_t n, int64_t heads, int64_t head_dim, int64_t t, int64_t window, float eps,
+                                  float** out, piper_hip_stream stream);
+
 /* Channel LayerNorm with fused residual: out = LN_c(x + y)·gamma + beta over C for each (n,t); y may be
  * NULL. Replaces Transpose + ReduceMean/Sub/Pow/Sqrt/Div/Mul/Add (GraphExecutor.swift:2071-2125). */
 int piper_hip_add_layernorm_f32(piper_hip_ctx* ctx, const float* x, const float* y, const float* gamma,
@@ -405,10 +415,10 @@ int piper_hip_voice_last_gpu_ms(piper_hip_voice* v, int slot, double* ms);
 /* Stream of a slot (for external event timing / profiling). */
 piper_hip_stream piper_hip_voice_slot_stream(piper_hip_voice* v, int slot);
 /* Per-kernel timing of the slot's schedule: runs the schedule eagerly `iters` times with a hipEvent pair
- * around every launch; fills up to `max_entries` entries sorted by schedule order. */
+ * around every launch and reports the median per launch; fills up to `max_entries` entries in schedule order. */
 typedef struct {
   char name[48];
-  double avg_us;     /* mean launch duration */
+  double avg_us;     /* MEDIAN launch duration over the profiled passes (robust against a stalled pass) */
   double flops;      /* algorithmic FLOPs of this launch (SURVEY.md Appendix A recipe) */
   double bytes;      /* algorithmic bytes of this launch (same recipe) */
 } piper_hip_kernel_stat;

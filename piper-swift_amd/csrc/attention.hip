@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv.h"
 
 namespace {
 
@@ -244,86 +245,102 @@ __global__ __launch_bounds__(kBlock) void rel_attention_kernel(const float* __re
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kAttWaves = 8;
 
-template <int D, int RV>
-__global__ __launch_bounds__(64 * kAttWaves) void rel_attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                           const float* __restrict__ v, const float* __restrict__ ek,
-                                                                           const float* __restrict__ ev, float* __restrict__ out, int T,
-                                                                           int w, int64_t in_batch_stride, int64_t out_batch_stride,
-                                                                           const int* __restrict__ len_ptr, int Tp) {
+// One head of the strip, run by NW waves (`wv` = this wave's index among them): scores → softmax → P·V (+ relative values).
+// `dst` receives out[c][i] with row stride `dst_ld` (the [H·d, T] tensor in global memory, or the block's [H·d][16] tile in
+// LDS when the o-projection is fused). Barriers are block-wide: every wave of the block calls this in lockstep.
+// Everything the later phases read from global memory that does not depend on the softmax — the first two key chunks of this
+// wave's V rows and its E_v column — is requested together with q and the first K tile, so the head costs ONE exposed memory
+// round trip instead of four (the phases are short; at T ≈ 100 the head is a latency chain, not arithmetic).
+template <int D, int RV, int NW>
+__device__ __forceinline__ void att_head(const float* __restrict__ qb, const float* __restrict__ kb, const float* __restrict__ vb,
+                                         const float* __restrict__ ek, const float* __restrict__ ev, float* __restrict__ dst, int dst_ld,
+                                         int dst_col0, int T, int Tv, int w, int i0, float* sc, float* qe, int Tp, int lane, int wv) {
   constexpr int NS = D / 4;   // contraction steps over the head dim
   constexpr int NCT = D / 16; // channel tiles of the output
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sc = smem;            // [RV][Tp] scores → probabilities
-  float* qe = smem + RV * Tp;  // [16][17] relative-key logits of the strip
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int CH = 8;       // P·V steps per prefetch chunk
+  constexpr int MAXW4 = 4;    // relative-value steps (2w+1 ≤ 16)
   const int r16 = lane & 15, kq = lane >> 4;
-  const int i0 = blockIdx.x * RV, h = blockIdx.y, n = blockIdx.z;
-  const int Tv = len_ptr ? min(len_ptr[n], T) : T;  // block-uniform true length
-  if (i0 >= Tv) return;
   const int W = 2 * w + 1;
-  const float* qb = q + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
-  const float* kb = k + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
-  const float* vb = v + (int64_t)n * in_batch_stride + (int64_t)h * D * T;
   const float scale = sqrtf((float)D);
   const int nkt = (Tv + 15) >> 4;  // key tiles; tile index nkt is the relative-key tile
+  const bool pi_ok = r16 < RV && i0 + r16 < Tv;
+  const int nsteps = (Tv + 3) >> 2;
 
-  // ---- 1. scores
+  static_assert(NS % 2 == 0, "head dim must be a multiple of 8");
+  constexpr int NH = NS / 2;  // a key tile is fetched in two halves of the contraction: one half in flight, one feeding the MFMAs
+  float qa[NS], b0[NH], b1[NH];
+  float a0[CH], a1[CH], arel[MAXW4];
+  auto load_half = [&](float (&b)[NH], int jt, int half) {
+    if (jt < nkt) {
+      const int j = jt * 16 + r16;
+      const int jc = min(j, Tv - 1);
+#pragma unroll
+      for (int s = 0; s < NH; s++) b[s] = kb[(int64_t)(4 * (half * NH + s) + kq) * T + jc];
+    } else {  // E_k[m][c] as B[k = c][n = m]
+      const int mc = min(r16, W - 1);
+#pragma unroll
+      for (int s = 0; s < NH; s++) b[s] = ek[mc * D + 4 * (half * NH + s) + kq];
+    }
+  };
+  auto load_v = [&](float (&a)[CH], const float* vrow, int s0) {
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      const int j = 4 * (s0 + u) + kq;
+      a[u] = vrow[min(j, Tv - 1)];
+    }
+  };
+  // ---- one burst of loads: q strip, first K tile, first V chunks and E_v column of this wave's first channel tile
   {
-    float qa[NS];
-    const bool row_ok = r16 < RV && i0 + r16 < Tv;
     const int qi = min(i0 + r16, Tv - 1);
 #pragma unroll
     for (int s = 0; s < NS; s++) qa[s] = qb[(int64_t)(4 * s + kq) * T + qi];
+    if (wv <= nkt) load_half(b0, wv, 0);
+    if (wv < NCT) {
+      const float* vrow = vb + (int64_t)(wv * 16 + r16) * T;
+      load_v(a0, vrow, 0);
+      load_v(a1, vrow, CH);
+#pragma unroll
+      for (int s = 0; s < MAXW4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + wv * 16 + r16];
+    }
+  }
+
+  // ---- 1. scores
+  {
+    const bool row_ok = pi_ok;
 #pragma unroll
     for (int s = 0; s < NS; s++) qa[s] = row_ok ? qa[s] / scale : 0.0f;  // Div of the graph: query / sqrt(k_channels)
-    float b0[NS], b1[NS];
-    auto load_tile = [&](float (&b)[NS], int jt) {
-      if (jt < nkt) {
-        const int j = jt * 16 + r16;
-        const int jc = min(j, Tv - 1);
-#pragma unroll
-        for (int s = 0; s < NS; s++) b[s] = kb[(int64_t)(4 * s + kq) * T + jc];
-      } else {  // E_k[m][c] as B[k = c][n = m]
-        const int mc = min(r16, W - 1);
-#pragma unroll
-        for (int s = 0; s < NS; s++) b[s] = ek[mc * D + 4 * s + kq];
-      }
-    };
-    auto compute_tile = [&](const float (&b)[NS], int jt) {
+    // two accumulators (even / odd steps): the 16x16x4 form needs 40 cycles between dependent issues, 32 between independent
+    for (int jt = wv; jt <= nkt; jt += NW) {  // wave-uniform
       const bool col_ok = jt < nkt ? (jt * 16 + r16 < Tv) : (r16 < W);
-      f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+      load_half(b1, jt, 1);
 #pragma unroll
-      for (int s = 0; s < NS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], col_ok ? b[s] : 0.0f, acc, 0, 0, 0);
+      for (int s = 0; s < NH; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], col_ok ? b0[s] : 0.0f, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s + 1], col_ok ? b0[s + 1] : 0.0f, acc1, 0, 0, 0);
+      }
+      if (jt + NW <= nkt) load_half(b0, jt + NW, 0);
+#pragma unroll
+      for (int s = 0; s < NH; s += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[NH + s], col_ok ? b1[s] : 0.0f, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[NH + s + 1], col_ok ? b1[s + 1] : 0.0f, acc1, 0, 0, 0);
+      }
       // D: row = 4·kq + r (query), col = r16 (key / relative position)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = 4 * kq + r;
+        const float val = acc0[r] + acc1[r];
         if (row < RV) {
-          if (jt < nkt) sc[row * Tp + jt * 16 + r16] = acc[r];
-          else qe[row * 17 + r16] = acc[r];
+          if (jt < nkt) sc[row * Tp + jt * 16 + r16] = val;
+          else qe[row * 17 + r16] = val;
         }
       }
-    };
-    // wave-uniform tile loop with the next tile's fragments in flight under the current tile's MFMAs
-    int jt = wave;
-    if (jt <= nkt) load_tile(b0, jt);
-    while (jt <= nkt) {
-      const int jn = jt + kAttWaves;
-      if (jn <= nkt) load_tile(b1, jn);
-      compute_tile(b0, jt);
-      jt = jn;
-      if (jt > nkt) break;
-      const int jn2 = jt + kAttWaves;
-      if (jn2 <= nkt) load_tile(b0, jn2);
-      compute_tile(b1, jt);
-      jt = jn2;
     }
   }
   __syncthreads();
 
   // ---- 2. softmax (softmax.metal:13-41: max, exp and sum, multiply by 1/sum), relative-key logits added on the way in
-  for (int r = wave; r < RV; r += kAttWaves) {
+  for (int r = wv; r < RV; r += NW) {
     const int ia = i0 + r;
     if (ia >= Tv) break;  // wave-uniform
     float* row = sc + r * Tp;
@@ -349,23 +366,18 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_mfma_kernel(cons
   }
   __syncthreads();
 
-  // ---- 3. P·V + relative-value term
-  if (wave < NCT) {
-    const int c0 = wave * 16;
+  // ---- 3. P·V + relative-value term: channel tiles wv, wv + NW, …
+  for (int ct = wv; ct < NCT; ct += NW) {
+    const int c0 = ct * 16;
     const float* vrow = vb + (int64_t)(c0 + r16) * T;        // A[m = channel][k = key]
-    const bool pi_ok = r16 < RV && i0 + r16 < Tv;            // B[k = key][n = query row]
-    const float* prow = sc + min(r16, RV - 1) * Tp;
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    constexpr int CH = 8;  // steps per prefetch chunk
-    const int nsteps = (Tv + 3) >> 2;
-    float a0[CH], a1[CH];
-    auto load_a = [&](float (&a)[CH], int s0) {
+    const float* prow = sc + min(r16, RV - 1) * Tp;          // B[k = key][n = query row]
+    if (ct != wv) {  // later tiles of this wave: their first chunks were not part of the opening burst
+      load_v(a0, vrow, 0);
+      load_v(a1, vrow, CH);
 #pragma unroll
-      for (int u = 0; u < CH; u++) {
-        const int j = 4 * (s0 + u) + kq;
-        a[u] = vrow[min(j, Tv - 1)];
-      }
-    };
+      for (int s = 0; s < MAXW4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + c0 + r16];
+    }
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
     auto run = [&](const float (&a)[CH], int s0) {
       float b[CH];
 #pragma unroll
@@ -374,36 +386,178 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_mfma_kernel(cons
         b[u] = prow[min(j, Tv - 1)];
       }
 #pragma unroll
-      for (int u = 0; u < CH; u++) {
+      for (int u = 0; u < CH; u += 2) {
         const int j = 4 * (s0 + u) + kq;
-        const bool ok = j < Tv;  // also false for the steps past nsteps of the last chunk
+        const bool ok = j < Tv, ok2 = j + 4 < Tv;  // also false for the steps past nsteps of the last chunk
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a[u] : 0.0f, (ok && pi_ok) ? b[u] : 0.0f, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(ok2 ? a[u + 1] : 0.0f, (ok2 && pi_ok) ? b[u + 1] : 0.0f, accb, 0, 0, 0);
       }
     };
-    load_a(a0, 0);
     for (int s0 = 0; s0 < nsteps; s0 += 2 * CH) {
-      if (s0 + CH < nsteps) load_a(a1, s0 + CH);
       run(a0, s0);
       if (s0 + CH >= nsteps) break;
-      if (s0 + 2 * CH < nsteps) load_a(a0, s0 + 2 * CH);
+      if (s0 + 2 * CH < nsteps) load_v(a0, vrow, s0 + 2 * CH);
       run(a1, s0 + CH);
+      if (s0 + 3 * CH < nsteps) load_v(a1, vrow, s0 + 3 * CH);
     }
     // relative values: A = E_v[m][c], B = P[i][i + m − w] (abs→rel skew as an index)
     const int ia = i0 + r16;
-    for (int s = 0; 4 * s < W; s++) {
+#pragma unroll
+    for (int s = 0; s < MAXW4; s++) {
       const int mrel = 4 * s + kq;
       const bool mok = mrel < W;
-      const float a = ev[min(mrel, W - 1) * D + c0 + r16];
       const int j = ia + mrel - w;
       const bool jok = mok && pi_ok && j >= 0 && j < Tv;
       const float b = prow[jok ? j : 0];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? a : 0.0f, jok ? b : 0.0f, acc, 0, 0, 0);
+      if (4 * s < W) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? arel[s] : 0.0f, jok ? b : 0.0f, acc, 0, 0, 0);
     }
     // D: row = channel 4·kq + r, col = query row r16
-    float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * D * T;
     if (pi_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) ob[(int64_t)(c0 + 4 * kq + r) * T + i0 + r16] = acc[r];
+      for (int r = 0; r < 4; r++) dst[(int64_t)(c0 + 4 * kq + r) * dst_ld + dst_col0 + r16] = acc[r] + accb[r];
+    }
+  }
+}
+
+template <int D, int RV>
+__global__ __launch_bounds__(64 * kAttWaves) void rel_attention_mfma_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                           const float* __restrict__ v, const float* __restrict__ ek,
+                                                                           const float* __restrict__ ev, float* __restrict__ out, int T,
+                                                                           int w, int64_t in_batch_stride, int64_t out_batch_stride,
+                                                                           const int* __restrict__ len_ptr, int Tp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sc = smem;            // [RV][Tp] scores → probabilities
+  float* qe = smem + RV * Tp;  // [16][17] relative-key logits of the strip
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i0 = blockIdx.x * RV, h = blockIdx.y, n = blockIdx.z;
+  const int Tv = len_ptr ? min(len_ptr[n], T) : T;  // block-uniform true length
+  if (i0 >= Tv) return;
+  const int64_t hoff = (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+  att_head<D, RV, kAttWaves>(q + hoff, k + hoff, v + hoff, ek, ev, out + (int64_t)n * out_batch_stride + (int64_t)h * D * T, T, i0, T, Tv, w, i0,
+                             sc, qe, Tp, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention BLOCK of an encoder layer in one launch: y = o_proj(rel_attention(q, k, v)); out = LN_c(x + y)·γ + β.
+// (GraphExecutor.swift: MatMul/Softmax/skew arms + Conv :1739-1810 + Add :741-779 + the LayerNorm chain :2071-2125.)
+// A block owns 16 columns (query rows) and ALL channels: it runs the heads one after the other into an [H·d][16] tile in
+// LDS, then the k = 1 output projection on that tile (v_mfma_f32_16x16x4_f32, 16-row tiles of the packed 16-wide weight
+// image over the 8 waves, bias first), adds the residual and normalises over the channels — which it can do exactly
+// (two passes: mean, then mean of squared deviations, like the graph's ReduceMean / Sub / Pow / ReduceMean) because every
+// channel of its columns is in the block. Replaces three launches (attention, conv_o, add+LayerNorm) and two round trips of
+// the [H·d, T] tensor through memory.
+template <int D>
+__global__ __launch_bounds__(64 * kAttWaves) void attention_block_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                        const float* __restrict__ v, const float* __restrict__ ek,
+                                                                        const float* __restrict__ ev, const float* __restrict__ wo16,
+                                                                        const float* __restrict__ bo, const float* __restrict__ xres,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        float* __restrict__ out, int H, int T, int w, int64_t in_batch_stride,
+                                                                        int64_t x_batch_stride, const int* __restrict__ len_ptr, int Tp,
+                                                                        int o_nsteps, float eps) {
+  constexpr int RV = 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sc = smem;                 // [2][16][Tp]: one strip per head of the pair in flight
+  float* qe = sc + 2 * RV * Tp;     // [2][16][17]
+  float* att = qe + 2 * 16 * 17;    // [H·D][16]: B operand of the projection (stride 16: conflict-free fragment reads)
+  const int C = H * D;
+  float* red = att + C * 16;        // [kAttWaves][16] column partials of the LayerNorm
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.x * RV, n = blockIdx.z;
+  const int Tv = len_ptr ? min(len_ptr[n], T) : T;
+  if (i0 >= Tv) return;
+  // two heads at a time, four waves each (Piper: H = 2, one pass): half the dependent phases of a head-after-head loop
+  for (int hp = 0; hp < H; hp += 2) {
+    const int hg = wave >> 2, wv = wave & 3;
+    const int h = min(hp + hg, H - 1);  // odd H: the second group repeats the last head (same values, written twice)
+    const int64_t hoff = (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+    att_head<D, RV, 4>(q + hoff, k + hoff, v + hoff, ek, ev, att + h * D * 16, 16, 0, T, Tv, w, i0, sc + hg * RV * Tp, qe + hg * 16 * 17, Tp, lane,
+                       wv);
+    __syncthreads();  // the strips are rewritten by the next pair; after the last pair: the tile is complete
+  }
+  // ---- output projection: row tile mt = 16 channels; waves take tiles wave, wave + 8, …  (C/16 = 12 tiles for Piper)
+  const int ntiles = C >> 4;
+  const bool col_ok = i0 + r16 < Tv;
+  const int colc = min(i0 + r16, Tv - 1);
+  const float* xb = xres + (int64_t)n * x_batch_stride;
+  constexpr int MAXT = 2;  // tiles per wave held in registers (C ≤ 256)
+  float val[MAXT][4];
+  float s1 = 0.0f;
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ti++) {
+    const int mt = wave + kAttWaves * ti;
+    if (mt < ntiles) {  // wave-uniform
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = bo[16 * mt + 4 * kq + r];  // bias first (CPUBackend.conv1d)
+      float res[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) res[r] = xb[(int64_t)(16 * mt + 4 * kq + r) * T + colc];
+      const float* wa = wo16 + (int64_t)mt * o_nsteps * 64 + lane;
+      const int nst = C >> 2;
+      for (int s0 = 0; s0 < nst; s0 += 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = wa[(s0 + u) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; u++) b[u] = att[(4 * (s0 + u) + kq) * 16 + r16];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        val[ti][r] = res[r] + acc[r];  // Add(x, y)
+        s1 += val[ti][r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) val[ti][r] = 0.0f;
+    }
+  }
+  // ---- LayerNorm over the channels of each column: D layout has the column on lane & 15, channels on (lane >> 4, register)
+  s1 += __shfl_xor(s1, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  if (lane < 16) red[wave * 16 + lane] = s1;
+  __syncthreads();
+  float mean = 0.0f;
+#pragma unroll
+  for (int wv = 0; wv < kAttWaves; wv++) mean += red[wv * 16 + r16];
+  mean = mean / (float)C;
+  __syncthreads();
+  float s2 = 0.0f;
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ti++) {
+    const int mt = wave + kAttWaves * ti;
+    if (mt < ntiles) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        val[ti][r] -= mean;
+        s2 += val[ti][r] * val[ti][r];
+      }
+    }
+  }
+  s2 += __shfl_xor(s2, 16, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (lane < 16) red[wave * 16 + lane] = s2;
+  __syncthreads();
+  float var = 0.0f;
+#pragma unroll
+  for (int wv = 0; wv < kAttWaves; wv++) var += red[wv * 16 + r16];
+  var = var / (float)C;
+  const float sd = sqrtf(var + eps);
+  float* ob = out + (int64_t)n * x_batch_stride;
+#pragma unroll
+  for (int ti = 0; ti < MAXT; ti++) {
+    const int mt = wave + kAttWaves * ti;
+    if (mt < ntiles && col_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = 16 * mt + 4 * kq + r;
+        ob[(int64_t)c * T + i0 + r16] = (val[ti][r] / sd) * gamma[c] + beta[c];
+      }
     }
   }
 }
@@ -419,6 +573,22 @@ int launch_att_mfma(hipStream_t s, const float* q, const float* k, const float* 
     (void)hipFuncSetAttribute((const void*)rel_attention_mfma_kernel<D, RV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   dim3 grid((unsigned)ph::ceil_div(T, RV), (unsigned)H, (unsigned)N);
   hipLaunchKernelGGL((rel_attention_mfma_kernel<D, RV>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp);
+  return 0;
+}
+
+template <int D>
+int launch_att_block(hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, const float* wo16,
+                     const float* bo, const float* xres, const float* gamma, const float* beta, float* out, int N, int H, int T, int w,
+                     int64_t in_bs, int64_t x_bs, const int* len_ptr, int o_nsteps, float eps) {
+  const int Tp = ((T + 31) / 32) * 32 + 2;
+  const size_t lds = ((size_t)2 * 16 * Tp + 2 * 16 * 17 + (size_t)H * D * 16 + kAttWaves * 16) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  static bool raised[ph::kMaxDevices] = {};
+  if (lds > 64 * 1024 && ph::lds_optin_needed(raised))
+    (void)hipFuncSetAttribute((const void*)attention_block_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid((unsigned)ph::ceil_div(T, 16), 1u, (unsigned)N);
+  hipLaunchKernelGGL((attention_block_kernel<D>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, wo16, bo, xres, gamma, beta, out, H, T, w,
+                     in_bs, x_bs, len_ptr, Tp, o_nsteps, eps);
   return 0;
 }
 
@@ -479,6 +649,29 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;
 }
+bool attention_block_eligible(int H, int d, int w, int T) {
+  static const bool off = getenv("PIPER_HIP_NO_ATT_BLOCK") != nullptr || getenv("PIPER_HIP_ATT_SCALAR") != nullptr;  // A/B switch
+  if (off || d != 96 || H * d > 256 || (H * d) % 32 || 2 * w + 1 > 16 || w < 0 || T > 2048 || T < 1) return false;
+  const int Tp = ((T + 31) / 32) * 32 + 2;
+  return ((size_t)2 * 16 * Tp + 2 * 16 * 17 + (size_t)H * d * 16 + kAttWaves * 16) * sizeof(float) <= 160 * 1024;
+}
+
+// attention + output projection + residual + LayerNorm in one launch (attention_block_kernel). wo16 = the 16-wide packed
+// fragment image of conv_o (pack_conv_weights(..., tm = 16)), o_nsteps its padded step count. Returns UNSUPPORTED (nothing
+// launched) outside the kernel's geometry: the caller schedules the three separate launches instead.
+int launch_attention_block(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev,
+                           const float* wo16, const float* bo, const float* xres, const float* gamma, const float* beta, float* out, int N,
+                           int H, int d, int T, int w, int64_t in_batch_stride, int64_t x_batch_stride, const int* len_ptr, int o_nsteps,
+                           float eps) {
+  if (N <= 0 || T <= 0) return PIPER_HIP_OK;
+  if (!attention_block_eligible(H, d, w, T) || N > 65535) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "attention_block: geometry not covered");
+  if (launch_att_block<96>(s, q, k, v, ek, ev, wo16, bo, xres, gamma, beta, out, N, H, T, w, in_batch_stride, x_batch_stride, len_ptr, o_nsteps,
+                           eps) != 0)
+    PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "attention_block: needs more than 160 KiB of LDS");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "attention_block launch failed: %s", hipGetErrorString(e));
+  return PIPER_HIP_OK;
+}
 }  // namespace ph
 
 PH_EXPORT int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, const float* k, const float* v,
@@ -498,4 +691,34 @@ PH_EXPORT int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, co
                                 (int)window, bs, bs, nullptr);
   if (rc) return rc;
   return ss.finish("rel_attention_f32");
+}
+
+PH_EXPORT int piper_hip_attention_block_f32(piper_hip_ctx* ctx, const float* q, const float* k, const float* v, const float* emb_rel_k,
+                                            const float* emb_rel_v, const float* w_o, const float* b_o, const float* x,
+                                            const float* gamma, const float* beta, int64_t n, int64_t heads, int64_t head_dim, int64_t t,
+                                            int64_t window, float eps, float** out, piper_hip_stream stream) {
+  PH_CHECK_CTX(ctx);
+  if (n < 0 || heads <= 0 || head_dim <= 0 || t < 0 || window < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "attention_block: bad shape");
+  if (n * heads * head_dim * t > 0x7fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "attention_block: tensor too large");
+  const int C = (int)(heads * head_dim);
+  const size_t cnt = (size_t)(n * C * t);
+  int rc = ph::ensure_out(ctx, out, cnt, 0);
+  if (rc) return rc;
+  if (cnt == 0) return PIPER_HIP_OK;
+  if (!q || !k || !v || !emb_rel_k || !emb_rel_v || !w_o || !b_o || !x || !gamma || !beta) PH_FAIL(PIPER_HIP_ERR_ARG, "attention_block: null input");
+  if (!ph::attention_block_eligible((int)heads, (int)head_dim, (int)window, (int)t))
+    PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "attention_block: covered geometry is head_dim 96, heads·head_dim ≤ 256, window ≤ 7, T ≤ 2048 — compose "
+                                       "rel_attention + conv1d + add_layernorm instead");
+  ph::StreamScope ss(ctx, stream);
+  void* pw = nullptr;
+  rc = ctx->pool.alloc(ph::packed_conv_floats(C, C, 1, 16) * sizeof(float), &pw);
+  if (rc) return rc;
+  ph::defer_free(ctx, pw);
+  ph::pack_conv_weights(ss.s, w_o, C, C, 1, (float*)pw, 16);
+  const int o_nsteps = (int)(ph::packed_conv_floats(C, C, 1, 16) / ((size_t)ph::ceil_div(C, 16) * 64));
+  const int64_t bs = (int64_t)C * t;
+  rc = ph::launch_attention_block(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, (const float*)pw, b_o, x, gamma, beta, *out, (int)n, (int)heads,
+                                  (int)head_dim, (int)t, (int)window, bs, bs, nullptr, o_nsteps, eps);
+  if (rc) return rc;
+  return ss.finish("attention_block_f32");
 }

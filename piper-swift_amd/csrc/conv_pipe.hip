@@ -21,6 +21,12 @@
 
 #include "conv_win.h"
 
+// PH_PIPE_ABL (tools/probe/pipeprobe): ablation bits for timing experiments — results are WRONG when set. 1: no weight-ring
+// loads in the loop; 2: no window staging after the prologue; 4: no epilogue stores; 8: no residual loads; 16: no LDS reads.
+#ifndef PH_PIPE_ABL
+#define PH_PIPE_ABL 0
+#endif
+
 namespace ph {
 namespace {
 
@@ -180,6 +186,9 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
   int gpos = 0;              // groups of the current tile consumed so far
   int phase = 0;             // ring slot of the next group = groups consumed since kernel start mod 8 (0 or 4: chunks hold 4·taps)
   auto load_a = [&](int slot, int ahead) {
+#if PH_PIPE_ABL & 1
+    if (gpos > 0) return;
+#endif
     const int g = gpos + ahead;
     const char* src = g < G ? wa_cur + (int64_t)g * 1024 : wa_next + (int64_t)(g - G) * 1024;
     a[slot] = *(const float4*)(src + lane16);
@@ -242,10 +251,12 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
     for (int ch = 0; ch < nch; ch++) {
       const bool last = ch + 1 == nch;
       // (1) next stage's window: global → registers, in flight during this chunk's MFMAs
+#if !(PH_PIPE_ABL & 2)
       if (!last) issue(cur, ch + 1);
       else if (has_next) issue(nxt, 0);
+#endif
       // (2) the residual of the epilogue, issued ahead of the last chunk
-      if (last && p.res) {
+      if (last && p.res && !(PH_PIPE_ABL & 8)) {
 #pragma unroll
         for (int j = 0; j < NTW; j++) {
           const int col = min(nb0 + (wn * NTW + j) * 32 + r, p.Lout - 1);
@@ -268,7 +279,13 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
 #pragma unroll
           for (int e = 0; e < 4; e++) {
 #pragma unroll
-            for (int j = 0; j < NTW; j++) b[slot][j][e] = win[lbase + sidx + 32 * j];
+            for (int j = 0; j < NTW; j++) {
+#if PH_PIPE_ABL & 16
+              b[slot][j][e] = (float)(sidx + e);
+#else
+              b[slot][j][e] = win[lbase + sidx + 32 * j];
+#endif
+            }
             c_n++;
             const bool wrap = c_n == kCP;
             c_n = wrap ? 0 : c_n;
@@ -318,8 +335,10 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
         phase = (phase + ngr) & (kRA - 1);
       }
       // (4) next stage's window: registers → the other LDS buffer (its last readers passed the previous barrier)
+#if !(PH_PIPE_ABL & 2)
       if (!last) commit(cur, lds + (bufsel ^ 1) * buf_floats);
       else if (has_next) commit(nxt, lds + (bufsel ^ 1) * buf_floats);
+#endif
       __syncthreads();
       bufsel ^= 1;
     }
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
         float v[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = acc[j][q];
-        if (p.res) {
+        if (p.res && !(PH_PIPE_ABL & 8)) {
 #pragma unroll
           for (int q = 0; q < 16; q++) v[q] += resv[j][q];
         }
@@ -355,7 +374,11 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
 #pragma unroll
         for (int q = 0; q < 16; q++) {
           const int co = co0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+#if PH_PIPE_ABL & 4
+          if (okc && co < p.Cout && v[q] == 1.2345e33f) yb[co * p.y_len + pos] = v[q];
+#else
           if (okc && co < p.Cout) yb[co * p.y_len + pos] = lrelu1(v[q], p.out_alpha);
+#endif
         }
       }
     }

@@ -12,6 +12,7 @@
 // Weights stay resident (packed once into MFMA fragment order); nothing is decoded or uploaded per call
 // (the reference re-decodes 401 initializers and re-uploads every Conv weight per synthesize: GraphExecutor.swift:187-189,
 // 1774-1780).  Utterances are independent, so a voice has several slots (stream + arena + graph) that overlap on the GPU.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
@@ -28,6 +29,11 @@ int validate_config(const piper_hip_voice_config* c);
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
                          int64_t out_batch_stride, const int* len_ptr);
+bool attention_block_eligible(int H, int d, int w, int T);
+int launch_attention_block(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev,
+                           const float* wo16, const float* bo, const float* xres, const float* gamma, const float* beta, float* out, int N,
+                           int H, int d, int T, int w, int64_t in_batch_stride, int64_t x_batch_stride, const int* len_ptr, int o_nsteps,
+                           float eps);
 }  // namespace ph
 
 using namespace ph;
@@ -886,22 +892,6 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     const auto& L = v->enc[l];
     const std::string p = "enc" + std::to_string(l) + ".";
     add_conv(v, s, p + "qkv", L.qkv, plain(x, qkv, H, 3 * H, T), T);
-    {
-      Step st;
-      st.name = p + "rel_attention";
-      st.tag = "rel_attention";
-      const float *ek = L.ek, *ev = L.ev;
-      const int nh = c.n_heads, w = c.window;
-      st.run = [=](hipStream_t q) {
-        return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
-                                    (int64_t)3 * H * T, (int64_t)H * T, nullptr);
-      };
-      // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
-      st.flops = NB * 2.0 * nh * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
-      st.bytes = NB * 4.0 * nh * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
-      s.steps.push_back(st);
-    }
-    add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T), T);
     auto add_ln = [&](const std::string& nm, const float* a, const float* b, const float* g, const float* be, float* out) {
       Step st;
       st.name = nm;
@@ -912,7 +902,42 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       };
       s.steps.push_back(st);
     };
+    // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
+    const double att_flops = NB * 2.0 * c.n_heads * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
+    const double att_bytes = NB * 4.0 * c.n_heads * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
+    if (L.o.w16 && attention_block_eligible(c.n_heads, d, c.window, T)) {
+      // attention + conv_o + Add + LayerNorm in one launch: the block owns every channel of its 16 columns
+      Step st;
+      st.name = p + "attention_o_add_ln1";
+      st.tag = "attention_block";
+      const float *ek = L.ek, *ev = L.ev, *wo = L.o.w16, *bo = L.o.bias, *g1 = L.g1, *b1 = L.b1;
+      const int nh = c.n_heads, w = c.window;
+      const int o_nsteps = (int)(packed_conv_floats(H, H, 1, 16) / ((size_t)ceil_div(H, 16) * 64));
+      st.run = [=](hipStream_t q) {
+        return launch_attention_block(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, wo, bo, x, g1, b1, x1, NB, nh, d, T, w,
+                                      (int64_t)3 * H * T, (int64_t)H * T, nullptr, o_nsteps, 1e-5f);
+      };
+      st.flops = att_flops + NB * conv_flops(H, H, 1, T);
+      st.bytes = att_bytes + NB * conv_bytes(H, H, 1, T);
+      s.steps.push_back(st);
+    } else {
+    {
+      Step st;
+      st.name = p + "rel_attention";
+      st.tag = "rel_attention";
+      const float *ek = L.ek, *ev = L.ev;
+      const int nh = c.n_heads, w = c.window;
+      st.run = [=](hipStream_t q) {
+        return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
+                                    (int64_t)3 * H * T, (int64_t)H * T, nullptr);
+      };
+      st.flops = att_flops;
+      st.bytes = att_bytes;
+      s.steps.push_back(st);
+    }
+    add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T), T);
     add_ln(p + "add_ln1", x, y, L.g1, L.b1, x1);
+    }
     {
       ConvArgs a = plain(x1, ff, H, c.ffn, T);
       a.padL = (kf - 1) / 2;
@@ -1676,7 +1701,8 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
   if (!out) return PIPER_HIP_OK;
   std::vector<hipEvent_t> ev((size_t)n + 1);
   for (auto& e : ev) PH_HIP(hipEventCreate(&e), PIPER_HIP_ERR_LAUNCH);
-  std::vector<double> acc((size_t)n, 0.0);
+  std::vector<std::vector<float>> samples((size_t)n);  // per launch: one delta per pass — the MEDIAN is reported (a stall of one
+                                                        // pass on a fresh box must not poison a row: BENCH_r01 showed a 324 µs enc2.qkv)
   int rc = PIPER_HIP_OK;
   for (int it = 0; it < iters + 1 && !rc; it++) {  // first pass is warm-up
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s.stream, (unsigned long long)(100 * (1500 + 12 * n)));  // µs → ticks
@@ -1691,7 +1717,7 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
     for (int i = 0; i < n; i++) {
       float ms = 0;
       PH_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), PIPER_HIP_ERR_LAUNCH);
-      acc[i] += ms * 1000.0;
+      samples[i].push_back(ms * 1000.0f);
     }
   }
   // event floor: the same bracket around an empty kernel (dispatch boundary + event markers, no work) — what has to be
@@ -1715,7 +1741,9 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
   for (int i = 0; i < n && i < max_entries; i++) {
     memset(&out[i], 0, sizeof out[i]);
     snprintf(out[i].name, sizeof out[i].name, "%s", s.steps[i].name.c_str());
-    out[i].avg_us = acc[i] / iters;
+    std::vector<float>& sm = samples[i];
+    std::sort(sm.begin(), sm.end());
+    out[i].avg_us = sm.empty() ? 0.0 : (sm.size() & 1 ? sm[sm.size() / 2] : 0.5 * (sm[sm.size() / 2 - 1] + sm[sm.size() / 2]));
     out[i].flops = s.steps[i].flops;
     out[i].bytes = s.steps[i].bytes;
   }

@@ -157,6 +157,7 @@ _PROTOS = {
     "piper_hip_random_draws_u32": (C.c_int, [c_vp, C.c_size_t, C.c_uint64, C.POINTER(c_vp), c_vp]),
     "piper_hip_rel_attention_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64,
                                               C.c_int64, C.c_int64, C.POINTER(c_vp), c_vp]),
+    "piper_hip_attention_block_f32": (C.c_int, [c_vp] * 11 + [C.c_int64] * 5 + [C.c_float, C.POINTER(c_vp), c_vp]),
     "piper_hip_add_layernorm_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64, C.c_float,
                                               C.POINTER(c_vp), c_vp]),
     "piper_hip_wavenet_layer_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int64,
@@ -526,6 +527,15 @@ class HipBackend:
         p = c_vp()
         _check(self.lib.piper_hip_rel_attention_f32(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(embRelK), _ptr(embRelV), n,
                                                     heads, headDim, t, window, C.byref(p), commandBuffer))
+        return self._out(p, [n, heads * headDim, t])
+
+    def attentionBlockF32(self, q, k, v, embRelK, embRelV, wO, bO, x, gamma, beta, n, heads, headDim, t, window, eps=1e-5,
+                          commandBuffer=None):
+        """LN(x + conv_o(rel_attention(q, k, v)))·gamma + beta in one launch."""
+        p = c_vp()
+        _check(self.lib.piper_hip_attention_block_f32(self.ctx, _ptr(q), _ptr(k), _ptr(v), _ptr(embRelK), _ptr(embRelV), _ptr(wO), _ptr(bO),
+                                                      _ptr(x), _ptr(gamma), _ptr(beta), n, heads, headDim, t, window, eps, C.byref(p),
+                                                      commandBuffer))
         return self._out(p, [n, heads * headDim, t])
 
     def addLayerNormF32(self, x, y, gamma, beta, n, c, t, eps=1e-5, commandBuffer=None):

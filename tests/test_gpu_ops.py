@@ -203,6 +203,27 @@ def test_rel_attention_equals_unfused_ops(backend):
     assert_close(b.downloadFloat32(fused), b.downloadFloat32(ot), 2e-5, "fused vs unfused composition")
 
 
+@pytest.mark.parametrize("T,N", [(1, 1), (14, 1), (40, 2), (112, 1), (130, 3), (896, 1)])
+def test_attention_block_equals_composition(T, N, backend):
+    """attention_block_f32 (one launch) vs the ORACLE's rel_attention → conv1d (k = 1) → add_layernorm per batch item."""
+    H, d, w = 2, 96, 4
+    Cc = H * d
+    q, k, v, x = (kd.sym(SD + 2000 + j + 10 * T, (N, Cc, T)) for j in range(4))
+    ek, ev = kd.sym(SD + 2005, (2 * w + 1, d), 0.1), kd.sym(SD + 2006, (2 * w + 1, d), 0.1)
+    wo, bo = kd.weight(SD + 2007, (Cc, Cc, 1), Cc), kd.sym(SD + 2008, (Cc,), 0.1)
+    g, be = 1 + kd.sym(SD + 2009, (Cc,), 0.1), kd.sym(SD + 2010, (Cc,), 0.1)
+    out, shp = backend.attentionBlockF32(*(up(backend, a) for a in (q, k, v, ek, ev, wo, bo, x, g, be)), N, H, d, T, w)
+    got = dl(backend, out, shp)
+    for n in range(N):
+        att = orc.rel_attention(q[n:n + 1], k[n:n + 1], v[n:n + 1], ek, ev, H, d, T, w)
+        y = orc.conv1d(att, wo, bo)
+        ref = orc.add_layernorm(x[n:n + 1], y, g, be)
+        assert_close(got[n], ref[0], OP_TOL, f"attention block T={T} item {n}")
+    with pytest.raises(ph.UnsupportedOp):  # outside the fused kernel's geometry: the caller composes the ops
+        backend.attentionBlockF32(*(up(backend, a) for a in (q[:, :128], k[:, :128], v[:, :128], ek[:, :64], ev[:, :64], wo[:128, :128], bo[:128],
+                                                            x[:, :128], g[:128], be[:128])), N, 2, 64, T, w)
+
+
 def test_add_layernorm(backend, golden_mods):
     sd = kd.case_seed("mod", 0)
     x, y = kd.sym(sd + 20, (1, 192, 14), 2.0), kd.sym(sd + 21, (1, 192, 14), 2.0)
