@@ -377,14 +377,23 @@ typedef struct {
 
 /* Samples `synthesize` will produce for this utterance (F · Π up_rates). */
 int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_utterance* u);
-/* Prepare (and cache) the static schedule + HIP graph + arena for this utterance's (T,F) and upload its
- * inputs; returns a slot id ≥ 0. A slot is an independent stream + arena, so several prepared utterances
- * can be launched back-to-back and overlap on the GPU. */
+/* Attach a plan for this utterance's bucket to `slot` (building and caching it if the voice has none idle) and upload the
+ * utterance's inputs; returns the slot id ≥ 0. Plans own a stream and an arena, so several prepared slots can be launched
+ * back-to-back and overlap on the GPU. */
 int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot);
-/* The same for `n` utterances of identical shape (equal T and equal Σ durations): they share ONE schedule whose kernels
- * carry a batch dimension, so a launch costs what one utterance costs in dispatches. Utterances of different shapes go
- * to different slots (bucket by shape). `collect` then returns the n waveforms back to back. */
+/* The same for `n` utterances in ONE schedule whose kernels carry a batch dimension, so a launch costs what one utterance
+ * costs in dispatches. The items may differ in length (ragged batch): the schedule is the bucket of the longest item, every
+ * length-aware kernel reads each item's true lengths from device memory — taps past an item's end read as zero padding and
+ * attention excludes the keys past it, i.e. the reference graph's x_mask / y_mask semantics — so each item's result is what
+ * it would be alone, and tiles entirely past an item's end cost (almost) nothing. Group items of similar length to limit the
+ * padding. `collect` returns the n waveforms back to back, each at its own length. */
 int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot);
+/* Plans (schedule + arena + HIP graph) are cached per voice by bucket — phonemes rounded up to 16, frames to 16 (64 beyond
+ * 1024) — and batch size, least recently used first out, so a (T, F) never seen before usually finds its graph ready and
+ * `prepare` is only the input upload ("warm"); a new bucket pays schedule construction + one validation pass + capture +
+ * instantiate once ("cold"). Reports the bucket of a prepared slot and the cache's size. */
+int piper_hip_voice_plan_info(const piper_hip_voice* v, int slot, int32_t* bucket_t, int32_t* bucket_f, int32_t* cached_plans,
+                              size_t* cached_bytes);
 /* Batch size of a prepared slot (0 if the slot is not prepared). */
 int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot);
 /* Enqueue the prepared slot's forward pass (one hipGraphLaunch). No host sync. */
@@ -406,7 +415,8 @@ int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u,
                                int64_t max_samples, int64_t* n_samples);
 /* Debug taps ⇔ GraphExecutor.execute(maxNodeIndex:) returning intermediates (GraphExecutor.swift:75-152):
  * copy a named intermediate of the slot's last run to host. Names: "enc_out" [H,T], "m_p" [inter,T],
- * "logs_p" [inter,T], "z_p" [inter,F], "z" [inter,F], "dec_pre" [up_initial,F]. */
+ * "logs_p" [inter,T], "z_p" [inter,F], "z" [inter,F], "dec_pre" [up_initial,F] — per batch item, compacted to the item's
+ * true T / F (the bucket's padding is not copied), items back to back. */
 int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name, float* host, size_t max_floats,
                         size_t* n_floats);
 /* GPU milliseconds of the slot's last completed launch (hipEvent pair on the slot's stream) ⇔

@@ -56,6 +56,11 @@ struct ConvArgs {
   const float* mrf_a = nullptr;
   const float* mrf_b = nullptr;
   float alpha2 = 0.0f;
+  // bucketed schedules: batch item n really holds len_ptr[n]·len_mul input positions per row (≤ Lin, the row stride); taps
+  // beyond read as zero padding, exactly as if the tensor ended there. null ⇒ Lin. Outputs past the true length are
+  // don't-care values (never read unmasked by anything downstream).
+  const int* len_ptr = nullptr;
+  int len_mul = 1;
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv

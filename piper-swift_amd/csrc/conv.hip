@@ -86,12 +86,13 @@ __global__ __launch_bounds__(kBlock) void conv_direct_kernel(const ConvArgs p) {
     const float* x3b = PRO == PRO_AVG3_LRELU ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
     const float* wr = p.w + (int64_t)co * cig * p.K;
     const int inX0 = xo * p.stride - p.padL;
+    const int Lv = true_len(p, n);
     for (int ci = 0; ci < cig; ci++) {
       const int64_t roff = (int64_t)(p.in_ch_base + p.in_ch_sign * (ciBase + ci)) * p.Lin;
       for (int k = 0; k < p.K; k++) {
         const int pos = inX0 + k * p.dil;
         const float v = load_b<PRO>(p, xb + roff, PRO == PRO_AVG3_LRELU ? x2b + roff : nullptr,
-                                    PRO == PRO_AVG3_LRELU ? x3b + roff : nullptr, pos, true);
+                                    PRO == PRO_AVG3_LRELU ? x3b + roff : nullptr, pos, true, Lv);
         acc += v * wr[ci * p.K + k];
       }
     }
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
   const float* xb = p.x + (int64_t)n * p.x_batch_stride;
   const float* x2b = PRO == PRO_AVG3_LRELU ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
   const float* x3b = PRO == PRO_AVG3_LRELU ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+  const int Lv = true_len(p, n);
+  if (p.len_ptr && t0 >= Lv) return;  // every output of this block lies past the true length ('same' convs: Lout = Lin); block-uniform
   float acc[COUT];
 #pragma unroll
   for (int co = 0; co < COUT; co++) acc[co] = p.bias ? p.bias[co] : 0.0f;
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
     for (int cb = 0; cb < W; cb += kSmallBT) {
       const int col = cb + tid;
       const int pos = lo + col;
-      const bool ok = col < W && pos >= 0 && pos < p.Lin;
+      const bool ok = col < W && pos >= 0 && pos < Lv;
       const int64_t poff = ok ? pos : 0;
       if (col < W) {
 #pragma unroll 8

@@ -38,6 +38,11 @@ struct ConvBf16Args {
   // ConvTranspose1d, stride s | K, K − s = 2·pad: GEMM rows = (phase ρ, co), tap j reads q + ⌊(ρ+pad)/s⌋ − j and the
   // result lands at output position s·q + ρ. Cout is the real channel count; the row count is s·Cout.
   int ct_stride = 0, ct_pad = 0;
+  // bucketed schedules: batch item n really has len_ptr[n]·len_mul OUTPUT positions (≤ the bucket's). The activation image
+  // written for the next conv gets zeros beyond them, so that the image's "zero outside [0, L)" invariant — which IS the next
+  // conv's zero padding — holds for the true length. null ⇒ everything up to y_len is real.
+  const int* len_ptr = nullptr;
+  int len_mul = 1;
 };
 
 // bf16 elements of the packed fragment images (including kBf16WeightPad)
@@ -49,7 +54,8 @@ int pack_conv_weights_bf16(hipStream_t s, const float* w, int Cout, int Cin, int
 int pack_convt_weights_bf16(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, int pad, uint16_t* packed);
 // fp32 [N][C][L] → C8 image of lrelu(x, alpha) (interior only: the image must have been zeroed once).
 // row = positions per channel block of the image (0 ⇒ c8_row_len(L))
-int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha, uint16_t* act, int64_t row = 0);
+int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha, uint16_t* act, int64_t row = 0,
+                const int* len_ptr = nullptr);  // positions ≥ len_ptr[n] are written as zeros
 
 // geometry the bf16 kernels cover (stride-1, ungrouped, Cin % 32 == 0, padding within the halo)
 bool conv_bf16_eligible(int Cout, int Cin, int K, int dil, int padL, int padR);

@@ -69,15 +69,16 @@ __global__ __launch_bounds__(kBT) void pack_convt_bf16_kernel(const float* __res
 
 // fp32 [N][C][L] → C8 image of lrelu(x): one thread per (channel block, position) writes 16 bytes
 __global__ __launch_bounds__(kBT) void pack_act_c8_kernel(const float* __restrict__ x, int C, int L, int64_t row, float alpha,
-                                                         uint16_t* __restrict__ act) {
+                                                         uint16_t* __restrict__ act, const int* __restrict__ len_ptr) {
   const int CB = (C + 7) >> 3;
   const int n = blockIdx.z, cb = blockIdx.y;
+  const int Lv = len_ptr ? min(len_ptr[n], L) : L;
   const float* xb = x + ((int64_t)n * C + cb * 8) * L;
   uint4* ab = (uint4*)act + ((int64_t)n * CB + cb) * row + kC8Halo;
   for (int pos = blockIdx.x * kBT + threadIdx.x; pos < L; pos += gridDim.x * kBT) {
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = (cb * 8 + e < C) ? lrelu1(xb[(int64_t)e * L + pos], alpha) : 0.0f;
+    for (int e = 0; e < 8; e++) v[e] = (cb * 8 + e < C && pos < Lv) ? lrelu1(xb[(int64_t)e * L + pos], alpha) : 0.0f;
     uint4 o;
     o.x = pack2_bf16(v[0], v[1]); o.y = pack2_bf16(v[2], v[3]); o.z = pack2_bf16(v[4], v[5]); o.w = pack2_bf16(v[6], v[7]);
     ab[pos] = o;
@@ -270,12 +271,13 @@ __global__ __launch_bounds__(kBT) void conv_bf16_kernel(const ConvBf16Multi mult
           if (okc && co0 + (q & 3) + 8 * (q >> 2) + 4 * h < p.Cout) p.y[yi[q]] = v[q];
       }
       if (p.act) {
+        const bool live = !p.len_ptr || pos < p.len_ptr[n] * p.len_mul;  // past the true length the image must hold zeros
 #pragma unroll
         for (int g = 0; g < 4; g++) {
           const int cg = co0 + 8 * g + 4 * h;  // first of 4 consecutive channels
           uint2 o;
-          o.x = pack2_bf16(lrelu1(v[4 * g], p.act_alpha), lrelu1(v[4 * g + 1], p.act_alpha));
-          o.y = pack2_bf16(lrelu1(v[4 * g + 2], p.act_alpha), lrelu1(v[4 * g + 3], p.act_alpha));
+          o.x = live ? pack2_bf16(lrelu1(v[4 * g], p.act_alpha), lrelu1(v[4 * g + 1], p.act_alpha)) : 0u;
+          o.y = live ? pack2_bf16(lrelu1(v[4 * g + 2], p.act_alpha), lrelu1(v[4 * g + 3], p.act_alpha)) : 0u;
           if (okc && cg < p.Cout) {
             uint2* ap = (uint2*)((uint4*)p.act + ((int64_t)n * ACB + (cg >> 3)) * p.act_row + kC8Halo + pos) + ((cg >> 2) & 1);
             *ap = o;
@@ -335,11 +337,11 @@ int pack_convt_weights_bf16(hipStream_t s, const float* w, int Cin, int Cout, in
   hipLaunchKernelGGL(pack_convt_bf16_kernel, dim3(grid), dim3(kBT), 0, s, w, Cin, Cout, K, stride, pad, packed, total);
   return PIPER_HIP_OK;
 }
-int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha, uint16_t* act, int64_t row) {
+int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha, uint16_t* act, int64_t row, const int* len_ptr) {
   if (N <= 0 || C <= 0 || L <= 0) return PIPER_HIP_OK;
   if (row <= 0) row = c8_row_len(L);
   const dim3 grid((unsigned)std::min<int64_t>(ceil_div(L, kBT), 1024), (unsigned)((C + 7) / 8), (unsigned)N);
-  hipLaunchKernelGGL(pack_act_c8_kernel, grid, dim3(kBT), 0, s, x, C, L, row, alpha, act);
+  hipLaunchKernelGGL(pack_act_c8_kernel, grid, dim3(kBT), 0, s, x, C, L, row, alpha, act, len_ptr);
   return PIPER_HIP_OK;
 }
 

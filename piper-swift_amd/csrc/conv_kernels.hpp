@@ -43,10 +43,12 @@ __device__ __forceinline__ typename AccSel<TM>::type mfma_t(float a, float b, ty
   else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ int true_len(const ConvArgs& p, int n) { return p.len_ptr ? min(p.len_ptr[n] * p.len_mul, p.Lin) : p.Lin; }
+
 template <int PRO>
 __device__ __forceinline__ float load_b(const ConvArgs& p, const float* xrow, const float* x2row, const float* x3row, int pos,
-                                        bool ch_ok) {
-  if (!ch_ok || pos < 0 || pos >= p.Lin) return 0.0f;
+                                        bool ch_ok, int Lv) {
+  if (!ch_ok || pos < 0 || pos >= Lv) return 0.0f;
   float v = xrow[pos];
   if constexpr (PRO == PRO_AVG3_LRELU) v = ((v + x2row[pos]) + x3row[pos]) / 3.0f;
   if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     const int tb = t0 - p.padL;
     // does any element of this tile's window fall outside [0, Lin)?  (wave-uniform)
     const int span_lo = tb + (p.dil < 0 ? (K - 1) * p.dil : 0), span_hi = tb + (p.dil > 0 ? (K - 1) * p.dil : 0) + TM * NT - 1;
-    const bool interior = span_lo >= 0 && span_hi < p.Lin;
+    const int Lv = true_len(p, n);  // wave-uniform
+    const bool interior = span_lo >= 0 && span_hi < Lv;
 
     auto body = [&](auto edge_tag) {
       constexpr bool EDGE = decltype(edge_tag)::value;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
 #pragma unroll
           for (int nt = 0; nt < NT; nt++) {
             const int pos = tb + k * p.dil + TM * nt + j;
-            if (pos >= 0 && pos < p.Lin) okbits |= 1ull << (k * NT + nt);
+            if (pos >= 0 && pos < Lv) okbits |= 1ull << (k * NT + nt);
           }
       }
       // D groups form a register ring: D−1 groups of loads are in flight while one group feeds the matrix pipe.  With
@@ -445,6 +448,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
   const float* xb = p.x + (int64_t)n * p.x_batch_stride;
   const float* x2b = NX == 3 ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
   const float* x3b = NX == 3 ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+  const int Lv = true_len(p, n);
 
   f32x16 acc[MT][NTW];
 #pragma unroll
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
       if (row < nrows) {
         const int col = seg * 64 + lane;
         const int pos = lo + col;
-        const bool ok = (2 * c0 + row) < p.Cin && pos >= 0 && pos < p.Lin;
+        const bool ok = (2 * c0 + row) < p.Cin && pos >= 0 && pos < Lv;
         float v = xr[0][i];
         if constexpr (NX == 3) v = ((v + xr[1][i]) + xr[2][i]) / 3.0f;
         if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);

@@ -467,7 +467,10 @@ int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs*
   g.WN = 4 / g.WM;
   g.NTW = 1;
   auto tiles_for = [&](int ntw) { return (int64_t)ceil_div(a.Lout, g.WN * ntw * 32) * ceil_div(MT, g.WM) * a.N * count; };
-  if (!avg && tiles_for(2) >= 4 * (int64_t)ctx->num_cus && g.WN * 2 * 32 + reach + 6 <= kMaxWp) g.NTW = 2;
+  // r2d probe: 128 channels × 21 504 columns 196 → 166 µs with two column tiles per wave (half the window halo per column,
+  // half the weight stream per MFMA); it stops paying when a block no longer gets ≥ 2 tiles
+  // (256 channels = two row groups: 115 → 120 µs, left at one)
+  if (!avg && MT <= 4 && tiles_for(2) >= 2 * (int64_t)ctx->num_cus && g.WN * 2 * 32 + reach + 6 <= kMaxWp) g.NTW = 2;
   if ((int64_t)kCh * a.Lin > 0x7fffffff || (int64_t)a.Cout * a.y_len > 0x7fffffff)
     PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv_pipe: a batch item's tensor exceeds 32-bit offsets");
   static const char* force = getenv("PIPER_HIP_PIPE_NTW");  // tuning hook

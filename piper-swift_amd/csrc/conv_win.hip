@@ -123,18 +123,19 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
     const int W4 = Wp >> 2;              // float4s per row
     const int WCH = (W4 + 63) >> 6;
     const int dump = p.Cin * Wp;         // lanes past the row end / rows past Cin store here (keeps the loads unconditional)
+    const int Lv = p.len_ptr ? min(p.len_ptr[n] * p.len_mul, p.Lin) : p.Lin;  // true input length of this batch item
     int row = wave, chunk = 0;
     while (row < p.Cin) {
       float4 t[kStage], t2[AVG ? kStage : 1], t3[AVG ? kStage : 1];
       int dst[kStage];
-      bool in[kStage];
+      int nvalid[kStage];
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
         const int rr = min(row, p.Cin - 1);
         const int i4 = chunk * 64 + lane;
-        const int pos = ga + 4 * i4;     // multiple of 4, rows are multiples of 4 long: all-in or all-out
-        in[q] = pos >= 0 && pos < p.Lin;
-        const int64_t off = (int64_t)rr * p.Lin + (in[q] ? pos : 0);
+        const int pos = ga + 4 * i4;     // multiple of 4; the row stride is a multiple of 4, the true length need not be
+        nvalid[q] = pos < 0 ? 0 : Lv - pos;  // leading components inside [0, Lv) (≥ 4: all of them)
+        const int64_t off = (int64_t)rr * p.Lin + ((pos >= 0 && pos < p.Lin) ? pos : 0);
         t[q] = *(const float4*)(xb + off);
         if constexpr (AVG) { t2[q] = *(const float4*)(xb2 + off); t3[q] = *(const float4*)(xb3 + off); }
         dst[q] = (row < p.Cin && i4 < W4) ? rr * Wp + 4 * i4 : dump;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
           v.z = ((v.z + t2[q].z) + t3[q].z) / 3.0f; v.w = ((v.w + t2[q].w) + t3[q].w) / 3.0f;
         }
         v.x = lrelu1(v.x, p.pro_alpha); v.y = lrelu1(v.y, p.pro_alpha); v.z = lrelu1(v.z, p.pro_alpha); v.w = lrelu1(v.w, p.pro_alpha);
-        if (!in[q]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        v.x = nvalid[q] > 0 ? v.x : 0.0f; v.y = nvalid[q] > 1 ? v.y : 0.0f; v.z = nvalid[q] > 2 ? v.z : 0.0f; v.w = nvalid[q] > 3 ? v.w : 0.0f;
         *(float4*)(win + dst[q]) = v;
       }
     }

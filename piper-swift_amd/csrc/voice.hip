@@ -156,7 +156,21 @@ struct Slot {
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  int T = -1, F = -1, NB = 1;  // NB utterances of identical (T, F) share one schedule (batch dimension of every kernel)
+  // A Slot is a PLAN: schedule + arena + graph for one bucket (kind, T, F, NB). T and F are the bucket's row lengths; the
+  // true lengths of the NB batch items live in device memory (lensT / lensF) where every length-aware kernel reads them, so
+  // one captured graph serves every utterance that fits the bucket — exactly (positions past a true length read as zero
+  // padding, attention excludes keys past it), not approximately.
+  int kind = 0;  // 0 = whole utterance, 1 = generator only (streaming window)
+  int T = -1, F = -1, NB = 1;
+  int prec = 0;            // generator precision the schedule was built for
+  bool in_use = false;     // attached to a user slot id
+  uint64_t last_use = 0;   // voice-wide clock value of the last attach (LRU)
+  size_t arena_bytes = 0;
+  int* lensT = nullptr;    // [NB] device: true phoneme count per item
+  int* lensF = nullptr;    // [NB] device: true frame count per item
+  std::vector<int> h_T, h_F;   // the same on the host (collect / tap / streaming)
+  int* h_lens = nullptr;       // pinned staging [2·NB]
+  size_t h_cap_lens = 0;
   // device buffers
   std::vector<void*> owned;
   int64_t* ids = nullptr;
@@ -169,7 +183,12 @@ struct Slot {
   float* audio = nullptr;
   int64_t n_samples = 0;
   std::vector<Step> steps;
-  std::map<std::string, std::pair<const float*, size_t>> taps;
+  struct Tap {  // a named intermediate: [NB] items of [C][row] floats, of which the first len_b (T or F of item b) are real
+    const float* p;
+    int C, row, unit;  // unit: 0 = phonemes (T), 1 = frames (F)
+    size_t batch_stride;
+  };
+  std::map<std::string, Tap> taps;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   bool timed = false;
@@ -227,8 +246,11 @@ struct piper_hip_voice {
   std::vector<ConvWB> up_b;                             // [stage]
   std::vector<std::vector<std::vector<ConvWB>>> rb_b;   // [stage][rb][conv]
   std::vector<void*> owned;
-  Slot slots[kMaxSlots];
-  std::map<int, std::unique_ptr<Slot>> gen_slots;  // streaming: generator-only schedules by window width (frames)
+  // Plans are cached voice-wide, least-recently-used first out; a user slot id is a handle on one of them. A TTS server sees
+  // a new (T, F) almost every call: with buckets the plan for it usually exists already (prepare = input upload only).
+  std::vector<std::unique_ptr<Slot>> plans;
+  Slot* attached[kMaxSlots] = {};
+  uint64_t use_clock = 0;
   int hop = 1;
 };
 
@@ -404,7 +426,8 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
   if (all && s.inited) {
     if (s.h_ids) (void)hipHostFree(s.h_ids);
     if (s.h_f2i) (void)hipHostFree(s.h_f2i);
-    s.h_ids = nullptr; s.h_f2i = nullptr; s.h_cap_t = s.h_cap_f = 0;
+    if (s.h_lens) (void)hipHostFree(s.h_lens);
+    s.h_ids = nullptr; s.h_f2i = nullptr; s.h_lens = nullptr; s.h_cap_t = s.h_cap_f = s.h_cap_lens = 0;
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
@@ -425,14 +448,14 @@ struct Arena {
     void* p = nullptr;
     if (rc) return nullptr;
     rc = v->ctx->pool.alloc((n ? n : 1) * sizeof(float), &p);
-    if (!rc) s->owned.push_back(p);
+    if (!rc) { s->owned.push_back(p); s->arena_bytes += (n ? n : 1) * sizeof(float); }
     return (float*)p;
   }
   void* raw(size_t bytes) {
     void* p = nullptr;
     if (rc) return nullptr;
     rc = v->ctx->pool.alloc(bytes ? bytes : 1, &p);
-    if (!rc) s->owned.push_back(p);
+    if (!rc) { s->owned.push_back(p); s->arena_bytes += bytes ? bytes : 1; }
     return p;
   }
 };
@@ -525,16 +548,18 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
   {
     Step st;
     st.name = "dec.z_to_bf16";
-    st.run = [=](hipStream_t q) { return pack_act_c8(q, z, NB, I, F, 1.0f, zc8); };
+    const int* lf = s.lensF;
+    st.run = [=](hipStream_t q) { return pack_act_c8(q, z, NB, I, F, 1.0f, zc8, 0, lf); };
     s.steps.push_back(st);
   }
   {
     ConvBf16Args a;
     a.x = zc8; a.y = dec0; a.act = a_in; a.act_alpha = 0.1f;  // the first stage's ConvTranspose reads lrelu(conv_pre)
     a.N = NB; a.dil = 1; a.padL = 3; a.Lout = F; a.x_row = (int)c8_row_len(F); a.act_row = (int)c8_row_len(F); a.y_len = F;
+    a.len_ptr = s.lensF; a.len_mul = 1;
     add_conv_bf16(v, s, "dec.conv_pre", v->conv_pre_b, a, NB * conv_flops(c.up_initial, I, 7, F));
   }
-  s.taps["dec_pre"] = {dec0, B * c.up_initial * F};
+  s.taps["dec_pre"] = {dec0, c.up_initial, F, 1, (size_t)c.up_initial * F};
   int L = F;
   const float* mean = nullptr;
   for (int u = 0; u < c.n_ups; u++) {
@@ -565,6 +590,7 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
       a.x = a_in; a.y = up; a.act = a_up; a.act_alpha = 0.1f;
       a.N = NB; a.Lout = L; a.x_row = (int)c8_row_len(L); a.act_row = row; a.y_len = Lo;
       a.ct_stride = S.stride; a.ct_pad = S.pad;
+      a.len_ptr = s.lensF; a.len_mul = Lo / F;
       add_conv_bf16(v, s, p + "lrelu_convT", v->up_b[u], a, NB * 2.0 * S.Cin * S.Cout * (double)S.K * L);
     }
     if (merged) {
@@ -585,6 +611,7 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
             ConvBf16Args a;
             a.x = in; a.N = NB; a.dil = d2; a.padL = (K * d2 - d2) / 2; a.Lout = Lo; a.x_row = row; a.act_row = row; a.y_len = Lo;
             a.act_alpha = 0.1f;
+            a.len_ptr = s.lensF; a.len_mul = Lo / F;
             return a;
           };
           float* dst = lastd ? (j == 2 ? m : r[j]) : tmp[j][di & 1];
@@ -641,6 +668,7 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
           ConvBf16Args a;
           a.x = in; a.N = NB; a.dil = dl; a.padL = (K * dl - dl) / 2; a.Lout = Lo; a.x_row = row; a.act_row = row; a.y_len = Lo;
           a.act_alpha = 0.1f;
+          a.len_ptr = s.lensF; a.len_mul = Lo / F;
           return a;
         };
         auto finish = [&](ConvBf16Args a) {  // the conv that closes the residual: x ← x + conv(…)
@@ -685,6 +713,7 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
     a.x = mean;
     a.prologue = PRO_LRELU; a.alpha = 0.01f;
     a.y = s.audio; a.N = NB; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.len_ptr = s.lensF; a.len_mul = L / F;
     a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
     a.epilogue = EPI_TANH;
     add_conv(v, s, "dec.conv_post_tanh", v->conv_post, a, L);
@@ -704,9 +733,12 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   if (c.n_rb != kWinMulti) return PIPER_HIP_ERR_UNSUPPORTED;
   // A/B switches: PIPER_HIP_NO_PIPE=1 keeps round 1's one-tile-per-block window kernel; PIPER_HIP_PIPE_MIN_F (frames × batch)
   // is the size below which the window kernel's in-block K-split still wins (very short utterances: fewer tiles than CUs)
+  // conv_pipe (persistent, chunk-pipelined) wins once a launch holds enough work to amortise its prologue and tail — the
+  // high voice's 128/256-channel stages: 89 vs 73 TFLOP/s — and loses to the one-tile-per-block window kernel on the medium
+  // voice at factor 8 (48 vs 46 µs per merged launch). Threshold on the launch's FLOPs; PIPER_HIP_PIPE_MIN_GFLOP overrides.
   static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
-  static const int pipe_min_f = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_F"); return e ? atoi(e) : 0; }();
-  const bool use_pipe = !no_pipe && (int64_t)NB * F >= pipe_min_f;
+  static const double pipe_min_flops = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
+  auto pipe_pays = [&](double launch_flops) { return !no_pipe && launch_flops >= pipe_min_flops; };
   {
     int L = F;
     for (int u = 0; u < c.n_ups; u++) {
@@ -742,13 +774,14 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       st.tag = "conv_mfma";
       st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;
       st.bytes = NB * 4.0 * ((double)S.Cin * L * (cur[1] ? 3 : 1) + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
-      const bool ct_pipe = use_pipe && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
+      const bool ct_pipe = pipe_pays(st.flops) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
       if (ct_pipe || (S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L))) {
         ConvWinArgs wa;
         wa.x = cur[0]; wa.x2 = cur[1]; wa.x3 = cur[2]; wa.w4 = ct_pipe ? S.up.w5 : S.up.w4; wa.bias = S.up.bias; wa.y = up;
         wa.pro_alpha = 0.1f;
         wa.N = NB; wa.Cin = S.Cin; wa.Cout = S.Cout; wa.K = S.K; wa.Lin = L; wa.Lout = L; wa.y_len = Lo;
         wa.ct_stride = S.stride; wa.ct_pad = S.pad;
+        wa.len_ptr = s.lensF; wa.len_mul = L / F;
         if (ct_pipe) st.run = [ctx, wa](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, &wa, 1); };
         else st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
       } else {
@@ -757,6 +790,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
         a.prologue = cur[1] ? PRO_AVG3_LRELU : PRO_LRELU;
         a.alpha = 0.1f;
         a.y = up; a.N = NB; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
+        a.len_ptr = s.lensF; a.len_mul = L / F;
         a.x_batch_stride = (int64_t)S.Cin * L; a.y_batch_stride = (int64_t)S.Cout * Lo; a.y_len = Lo;
         a.epilogue = EPI_CONVT; a.ct_stride = S.stride; a.ct_padL = S.pad; a.ct_Lout = Lo;
         a.w = S.up.w; a.w16 = S.up.w16; a.bias = S.up.bias; a.Cin = S.up.Cin; a.Cout = S.up.Cout; a.K = S.up.K;
@@ -769,7 +803,9 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
                          const float* const res[kWinMulti], float* const y[kWinMulti], const int dil[kWinMulti]) {
       struct Pack { ConvWinArgs a[kWinMulti]; } pk;
       double fl = 0, by = 0;
-      bool pipe = use_pipe;
+      double launch_fl = 0;
+      for (int j = 0; j < kWinMulti; j++) launch_fl += NB * conv_flops(ws[j]->Cout, ws[j]->Cin, ws[j]->K, Lo);
+      bool pipe = pipe_pays(launch_fl);
       for (int j = 0; j < kWinMulti; j++)
         pipe = pipe && ws[j]->w5 && conv_pipe_eligible(ws[j]->Cout, ws[j]->Cin, ws[j]->K, dil[j], (ws[j]->K * dil[j] - dil[j]) / 2, Lo, Lo);
       for (int j = 0; j < kWinMulti; j++) {
@@ -779,6 +815,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
         wa.pro_alpha = 0.1f;
         wa.N = NB; wa.Cin = w.Cin; wa.Cout = w.Cout; wa.K = w.K; wa.dil = dil[j]; wa.padL = (w.K * dil[j] - dil[j]) / 2;
         wa.Lin = Lo; wa.Lout = Lo; wa.y_len = Lo;
+        wa.len_ptr = s.lensF; wa.len_mul = Lo / F;
         fl += NB * conv_flops(w.Cout, w.Cin, w.K, Lo);
         by += NB * conv_bytes(w.Cin, w.Cout, w.K, Lo);
       }
@@ -819,6 +856,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
     a.x = cur[0]; a.x2 = cur[1]; a.x3 = cur[2];
     a.prologue = PRO_AVG3_LRELU; a.alpha = 0.01f;  // F.leaky_relu default slope before conv_post, on the MRF mean
     a.y = s.audio; a.N = NB; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.len_ptr = s.lensF; a.len_mul = L / F;
     a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
     a.epilogue = EPI_TANH;
     add_conv(v, s, "dec.mrfmean_conv_post_tanh", v->conv_post, a, L);
@@ -833,15 +871,28 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   slot_release(v, s, false);
   static const bool parallel_rb = getenv("PIPER_HIP_PARALLEL_RB") != nullptr;
   static const bool use_win = getenv("PIPER_HIP_NO_WIN") == nullptr;  // window kernel for the generator's long rows
+  static const bool no_pipe1 = getenv("PIPER_HIP_NO_PIPE") != nullptr;
+  static const double pipe_min_flops1 = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
+  auto pipe_pays1 = [&](double launch_flops) { return !no_pipe1 && launch_flops >= pipe_min_flops1; };
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;
+  s.kind = gen_only ? 1 : 0;
+  s.prec = v->precision;
+  s.arena_bytes = 0;
   s.parallel = parallel_rb;
   const size_t B = (size_t)NB;
-  auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L) {
+  s.lensT = (int*)ar.raw(B * sizeof(int));
+  s.lensF = (int*)ar.raw(B * sizeof(int));
+  if (ar.rc) return ar.rc;
+  const int* lensT = s.lensT;
+  const int* lensF = s.lensF;
+  // lens = the per-item true lengths the rows of this conv are measured in (phonemes or frames), mul = positions per unit
+  auto plain = [&](const float* in, float* out, int Cin_, int Cout_, int L, const int* lens, int mul = 1) {
     ConvArgs a;
     a.x = in; a.y = out; a.N = NB; a.Lin = L; a.Lout = L; a.x_batch_stride = (int64_t)Cin_ * L; a.y_batch_stride = (int64_t)Cout_ * L;
     a.y_len = L;
+    a.len_ptr = lens; a.len_mul = mul;
     return a;
   };
   const float* z = nullptr;
@@ -891,7 +942,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   for (int l = 0; l < c.n_layers; l++) {
     const auto& L = v->enc[l];
     const std::string p = "enc" + std::to_string(l) + ".";
-    add_conv(v, s, p + "qkv", L.qkv, plain(x, qkv, H, 3 * H, T), T);
+    add_conv(v, s, p + "qkv", L.qkv, plain(x, qkv, H, 3 * H, T, lensT), T);
     auto add_ln = [&](const std::string& nm, const float* a, const float* b, const float* g, const float* be, float* out) {
       Step st;
       st.name = nm;
@@ -915,7 +966,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       const int o_nsteps = (int)(packed_conv_floats(H, H, 1, 16) / ((size_t)ceil_div(H, 16) * 64));
       st.run = [=](hipStream_t q) {
         return launch_attention_block(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, wo, bo, x, g1, b1, x1, NB, nh, d, T, w,
-                                      (int64_t)3 * H * T, (int64_t)H * T, nullptr, o_nsteps, 1e-5f);
+                                      (int64_t)3 * H * T, (int64_t)H * T, lensT, o_nsteps, 1e-5f);
       };
       st.flops = att_flops + NB * conv_flops(H, H, 1, T);
       st.bytes = att_bytes + NB * conv_bytes(H, H, 1, T);
@@ -929,32 +980,30 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       const int nh = c.n_heads, w = c.window;
       st.run = [=](hipStream_t q) {
         return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
-                                    (int64_t)3 * H * T, (int64_t)H * T, nullptr);
+                                    (int64_t)3 * H * T, (int64_t)H * T, lensT);
       };
       st.flops = att_flops;
       st.bytes = att_bytes;
       s.steps.push_back(st);
     }
-    add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T), T);
+    add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T, lensT), T);
     add_ln(p + "add_ln1", x, y, L.g1, L.b1, x1);
     }
     {
-      ConvArgs a = plain(x1, ff, H, c.ffn, T);
+      ConvArgs a = plain(x1, ff, H, c.ffn, T, lensT);
       a.padL = (kf - 1) / 2;
       a.epilogue = EPI_RELU;
       add_conv(v, s, p + "ffn1_relu", L.f1, a, T);
-      ConvArgs b = plain(ff, y, c.ffn, H, T);
+      ConvArgs b = plain(ff, y, c.ffn, H, T, lensT);
       b.padL = (kf - 1) / 2;
       add_conv(v, s, p + "ffn2", L.f2, b, T);
     }
     add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
   }
-  s.taps["enc_out"] = {x, B * H * T};
-  add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T), T);
-  if (NB == 1) {  // halves of the [2I, T] projection; for a batch read "enc_out"/"z_p" instead
-    s.taps["m_p"] = {stats, (size_t)I * T};
-    s.taps["logs_p"] = {stats + (size_t)I * T, (size_t)I * T};
-  }
+  s.taps["enc_out"] = {x, H, T, 0, (size_t)H * T};
+  add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T, lensT), T);
+  s.taps["m_p"] = {stats, I, T, 0, (size_t)2 * I * T};  // halves of the [2I, T] projection
+  s.taps["logs_p"] = {stats + (size_t)I * T, I, T, 0, (size_t)2 * I * T};
   {
     Step st;
     st.name = "expand_noise";
@@ -972,7 +1021,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     st.bytes = NB * 2.0 * 4.0 * ((double)F * T + (double)T * I + (double)F * I);
     s.steps.push_back(st);
   }
-  s.taps["z_p"] = {zp_tap, B * I * F};
+  s.taps["z_p"] = {zp_tap, I, F, 1, (size_t)I * F};
   // ---------------- flow (reverse)
   bool flipped = false;
   const int half = I / 2;
@@ -981,18 +1030,18 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     const auto& C = v->flows[f];
     const std::string p = "flow" + std::to_string(f) + ".";
     {
-      ConvArgs a = plain(zp, h, I, H, F);
+      ConvArgs a = plain(zp, h, I, H, F, lensF);
       a.in_ch_base = flipped ? I - 1 : 0;
       a.in_ch_sign = flipped ? -1 : 1;
       add_conv(v, s, p + "pre", C.pre, a, F);
     }
     for (int i = 0; i < c.wn_layers; i++) {
       const bool last = i + 1 == c.wn_layers;
-      ConvArgs a = plain(h, acts, H, H, F);
+      ConvArgs a = plain(h, acts, H, H, F, lensF);
       a.padL = (c.wn_kernel - 1) / 2;
       a.gate = 1;
       add_conv(v, s, p + "wn" + std::to_string(i) + ".in_gate", C.in[i], a, F);
-      ConvArgs b = plain(acts, h, H, H, F);
+      ConvArgs b = plain(acts, h, H, H, F, lensF);
       b.y2 = skip; b.y2_batch_stride = (int64_t)H * F;
       b.skip = i == 0 ? nullptr : skip;
       if (last) b.epilogue = EPI_WN_SKIP_LAST;
@@ -1000,7 +1049,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       add_conv(v, s, p + "wn" + std::to_string(i) + ".res_skip", C.rs[i], b, F);
     }
     {
-      ConvArgs a = plain(skip, zp, H, I, F);
+      ConvArgs a = plain(skip, zp, H, I, F, lensF);
       a.epilogue = EPI_RSUB;
       a.res = zp;
       a.out_ch_base = flipped ? I - 1 - half : half;
@@ -1022,15 +1071,15 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   }
   s.z_out = z;
   }  // !gen_only
-  s.taps["z"] = {z, B * I * F};
+  s.taps["z"] = {z, I, F, 1, (size_t)I * F};
   if (v->precision == PIPER_HIP_PRECISION_BF16) return build_generator_bf16(v, s, ar, z, dec0, F, NB);
   // ---------------- HiFi-GAN generator
   {
-    ConvArgs a = plain(z, dec0, I, c.up_initial, F);
+    ConvArgs a = plain(z, dec0, I, c.up_initial, F, lensF);
     a.padL = 3;
     add_conv(v, s, "dec.conv_pre", v->conv_pre, a, F);
   }
-  s.taps["dec_pre"] = {dec0, B * c.up_initial * F};
+  s.taps["dec_pre"] = {dec0, c.up_initial, F, 1, (size_t)c.up_initial * F};
   static const bool no_merge = getenv("PIPER_HIP_NO_MERGED_RB") != nullptr;
   // Advancing the three ResBlocks in one launch pays while a single conv cannot fill the chip (short utterances, small
   // batches); with many tiles per conv (NB·F large) the per-conv schedule with the mean fused into its producer is faster
@@ -1066,19 +1115,24 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       a.prologue = cur_is_mrf ? PRO_NONE : PRO_LRELU;  // the MRF mean kernel already applied LeakyReLU(0.1)
       a.alpha = 0.1f;
       a.y = up; a.N = NB; a.dil = -1; a.padL = 0; a.Lin = L; a.Lout = (Lo - 1 + S.pad) / S.stride + 1;
+      a.len_ptr = s.lensF; a.len_mul = L / F;
       a.x_batch_stride = (int64_t)S.Cin * L; a.y_batch_stride = (int64_t)S.Cout * Lo; a.y_len = Lo;
       a.epilogue = EPI_CONVT; a.ct_stride = S.stride; a.ct_padL = S.pad; a.ct_Lout = Lo;
       a.w = S.up.w; a.w16 = S.up.w16; a.bias = S.up.bias; a.Cin = S.up.Cin; a.Cout = S.up.Cout; a.K = S.up.K;
       Step st;
       st.name = p + "lrelu_convT";
       st.tag = "conv_mfma";
-      if (use_win && S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L)) {
+      const double ct_flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;
+      const bool ct_pipe1 = use_win && pipe_pays1(ct_flops) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
+      if (ct_pipe1 || (use_win && S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L))) {
         ConvWinArgs wa;
-        wa.x = cur[0]; wa.w4 = S.up.w4; wa.bias = S.up.bias; wa.y = up;
+        wa.x = cur[0]; wa.w4 = ct_pipe1 ? S.up.w5 : S.up.w4; wa.bias = S.up.bias; wa.y = up;
         wa.pro_alpha = cur_is_mrf ? 1.0f : 0.1f;
         wa.N = NB; wa.Cin = S.Cin; wa.Cout = S.Cout; wa.K = S.K; wa.Lin = L; wa.Lout = L; wa.y_len = Lo;
         wa.ct_stride = S.stride; wa.ct_pad = S.pad;
-        st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
+        wa.len_ptr = s.lensF; wa.len_mul = L / F;
+        if (ct_pipe1) st.run = [ctx, wa](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, &wa, 1); };
+        else st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
       } else
       st.run = [ctx, a](hipStream_t q) { return launch_conv_mfma(ctx, q, a); };
       st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;  // convT(Cin,Cout,K,s,Lin)
@@ -1106,7 +1160,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
         float* dst = lastd ? (fuse_mean ? m : r[j]) : ((di & 1) ? tmp2[j] : tmp[j]);
         const std::string nm = p + "rb" + std::to_string(j) + ".c" + std::to_string(di);
         auto rbconv = [&](const float* in, const float* res, float* out, int dl) {
-          ConvArgs a = plain(in, out, S.Cout, S.Cout, Lo);
+          ConvArgs a = plain(in, out, S.Cout, S.Cout, Lo, lensF, Lo / F);
           a.dil = dl; a.padL = (K * dl - dl) / 2; a.prologue = PRO_LRELU; a.alpha = 0.1f; a.res = res;
           return a;
         };
@@ -1129,10 +1183,15 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
           if (a.epilogue == EPI_MRF_MEAN) { wa.mrf_a = a.mrf_a; wa.mrf_b = a.mrf_b; wa.out_alpha = a.alpha2; }
           wa.N = NB; wa.Cin = w.Cin; wa.Cout = w.Cout; wa.K = w.K; wa.dil = a.dil; wa.padL = a.padL;
           wa.Lin = Lo; wa.Lout = Lo; wa.y_len = Lo;
+          wa.len_ptr = s.lensF; wa.len_mul = Lo / F;
           Step st;
           st.name = name;
-          st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
           st.flops = NB * conv_flops(w.Cout, w.Cin, w.K, Lo);
+          if (pipe_pays1(st.flops) && w.w5 && conv_pipe_eligible(w.Cout, w.Cin, w.K, a.dil, a.padL, Lo, Lo)) {
+            wa.w4 = w.w5;
+            st.run = [ctx, wa](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, &wa, 1); };
+          } else
+          st.run = [ctx, wa](hipStream_t q) { return launch_conv_win(ctx, q, wa); };
           st.bytes = NB * conv_bytes(w.Cin, w.Cout, w.K, Lo);
           st.lane = s.cur_lane;
           st.tag = "conv_mfma";
@@ -1180,6 +1239,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     a.x = cur[0];
     a.prologue = PRO_NONE;  // LeakyReLU(0.01) of the MRF mean was applied by the mean kernel
     a.y = s.audio; a.N = NB; a.padL = 3; a.Lin = L; a.Lout = L;
+    a.len_ptr = s.lensF; a.len_mul = L / F;
     a.x_batch_stride = (int64_t)v->conv_post.Cin * L; a.y_batch_stride = L; a.y_len = L;
     a.epilogue = EPI_TANH;
     add_conv(v, s, "dec.conv_post_tanh", v->conv_post, a, L);
@@ -1375,9 +1435,9 @@ PH_EXPORT int piper_hip_voice_set_precision(piper_hip_voice* v, int precision) {
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_set_precision: packing failed: %s", hipGetErrorString(e));
   }
-  for (auto& s : v->slots) slot_release(v, s, false);  // schedules are rebuilt by the next prepare
-  for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
-  v->gen_slots.clear();
+  for (auto& pl : v->plans) slot_release(v, *pl, true);  // every plan was built for the old precision: the next prepare rebuilds
+  v->plans.clear();
+  for (auto& at : v->attached) at = nullptr;
   v->precision = precision;
   return PIPER_HIP_OK;
 }
@@ -1388,8 +1448,7 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
   if (!v) return;
   (void)hipSetDevice(v->ctx->device);
   (void)hipDeviceSynchronize();
-  for (auto& s : v->slots) slot_release(v, s, true);
-  for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
+  for (auto& pl : v->plans) slot_release(v, *pl, true);
   for (void* p : v->owned) (void)v->ctx->pool.release(p);
   delete v;
 }
@@ -1400,31 +1459,143 @@ PH_EXPORT int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const pi
   return F * v->hop;
 }
 
+namespace {
+
+// Buckets: phoneme rows in steps of 16 (the tile width of the short-row kernels), frame rows in steps of 16 up to 1024 frames
+// and 64 beyond (long utterances: ≤ 6 % padding, far fewer distinct graphs).
+int bucket_t(int T) { return (int)ceil_div(T, 16) * 16; }
+int bucket_f(int F) { return F <= 1024 ? (int)ceil_div(F, 16) * 16 : (int)ceil_div(F, 64) * 64; }
+
+constexpr size_t kPlanCacheMax = 48;                    // plans kept per voice …
+constexpr size_t kPlanCacheBytes = (size_t)24 << 30;    // … and arena bytes (of 288 GB): least recently used idle plans go first
+
+Slot* slot_plan(const piper_hip_voice* v, int slot) {
+  if (!v || slot < 0 || slot >= kMaxSlots) return nullptr;
+  Slot* p = v->attached[slot];
+  return (p && p->exec) ? p : nullptr;
+}
+
+void evict_idle_plans(piper_hip_voice* v) {
+  auto total = [&]() { size_t b = 0; for (auto& p : v->plans) b += p->arena_bytes; return b; };
+  while (v->plans.size() > kPlanCacheMax || total() > kPlanCacheBytes) {
+    int victim = -1;
+    for (int i = 0; i < (int)v->plans.size(); i++)
+      if (!v->plans[i]->in_use && (victim < 0 || v->plans[i]->last_use < v->plans[victim]->last_use)) victim = i;
+    if (victim < 0) return;  // everything is attached: nothing to evict
+    Slot& d = *v->plans[victim];
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    slot_release(v, d, true);
+    v->plans.erase(v->plans.begin() + victim);
+  }
+}
+
+// An idle plan for (kind, Tb, Fb, NB) at the voice's precision, built (schedule + eager validation pass + graph capture) if
+// the cache has none. *built reports whether this call paid for a build ("cold" prepare).
+int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** out, bool* built) {
+  *built = false;
+  for (auto& p : v->plans)
+    if (!p->in_use && p->exec && p->kind == kind && p->T == Tb && p->F == Fb && p->NB == NB && p->prec == v->precision) {
+      *out = p.get();
+      return PIPER_HIP_OK;
+    }
+  std::unique_ptr<Slot> np(new Slot());
+  int rc = slot_init(v, *np);
+  if (rc) { slot_release(v, *np, true); return rc; }
+  if ((rc = build_schedule(v, *np, Tb, Fb, NB, kind == 1))) { slot_release(v, *np, true); return rc; }
+  Slot& s = *np;
+  // the validation pass and the capture run on whatever the arena holds: give the length arrays legal values first
+  {
+    std::vector<int> full((size_t)2 * NB);
+    for (int b = 0; b < NB; b++) { full[b] = Tb; full[NB + b] = Fb; }
+    hipError_t e = hipMemcpyAsync(s.lensT, full.data(), NB * sizeof(int), hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.lensF, full.data() + NB, NB * sizeof(int), hipMemcpyHostToDevice, s.stream);
+    if (e == hipSuccess && s.ids) e = hipMemsetAsync(s.ids, 0, (size_t)NB * Tb * sizeof(int64_t), s.stream);
+    if (e == hipSuccess && s.frame2id) e = hipMemsetAsync(s.frame2id, 0, (size_t)NB * Fb * sizeof(int32_t), s.stream);
+    if (e == hipSuccess && s.rng) e = hipMemsetAsync(s.rng, 0, (size_t)NB * 2 * sizeof(unsigned), s.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e != hipSuccess) { slot_release(v, s, true); PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: arena initialisation failed: %s", hipGetErrorString(e)); }
+  }
+  // one eager pass validates every launch (and sets kernel attributes) before capture
+  if ((rc = run_schedule(s, s.stream, false))) { slot_release(v, s, true); return rc; }
+  hipError_t e = hipStreamSynchronize(s.stream);
+  if (e != hipSuccess) {
+    slot_release(v, s, true);
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
+  }
+  if ((e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) {
+    slot_release(v, s, true);
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: begin capture failed: %s", hipGetErrorString(e));
+  }
+  // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
+  // short kernels gain), so that graph stays a single chain unless asked otherwise. The bf16 generator's builder decides
+  // for itself (s.parallel).
+  rc = run_schedule(s, s.stream, s.parallel);
+  hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
+  if (rc || ce != hipSuccess) {
+    slot_release(v, s, true);
+    if (rc) return rc;
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph capture failed: %s", hipGetErrorString(ce));
+  }
+  ce = hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0);
+  if (ce != hipSuccess) {
+    slot_release(v, s, true);
+    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph instantiate failed: %s", hipGetErrorString(ce));
+  }
+  *out = np.get();
+  v->plans.push_back(std::move(np));
+  *built = true;
+  return PIPER_HIP_OK;
+}
+
+void detach(piper_hip_voice* v, int slot) {
+  Slot* p = v->attached[slot];
+  if (!p) return;
+  if (p->stream) (void)hipStreamSynchronize(p->stream);  // its last launch may still be running / reading the inputs
+  p->in_use = false;
+  p->st_next = -1;
+  v->attached[slot] = nullptr;
+}
+
+}  // namespace
+
 PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot) {
   if (!v || !utts) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
   if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
-  int64_t F64 = 0;
-  int rc = check_utt(v, &utts[0], &F64);
-  if (rc) return rc;
-  for (int b = 1; b < n; b++) {  // one schedule serves the batch: every utterance must have the same (T, F)
+  if (slot < 0 || slot >= kMaxSlots) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d out of range [0,%d)", slot, kMaxSlots);
+  // the batch items may differ in length: the plan is the bucket of the longest, each item carries its own true lengths
+  int Tmax = 0, rc;
+  int64_t Fmax = 0;
+  std::vector<int> hT(n), hF(n);
+  for (int b = 0; b < n; b++) {
     int64_t Fb = 0;
     if ((rc = check_utt(v, &utts[b], &Fb))) return rc;
-    if (utts[b].t != utts[0].t || Fb != F64)
-      PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch item %d has (T=%d, F=%lld); the batch is (T=%d, F=%lld) — bucket utterances by shape", b,
-              utts[b].t, (long long)Fb, utts[0].t, (long long)F64);
+    if (utts[b].noise_mode != PIPER_HIP_NOISE_INJECTED && utts[b].noise_mode != PIPER_HIP_NOISE_DEVICE)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: unknown noise_mode %d", b, utts[b].noise_mode);
+    hT[b] = utts[b].t;
+    hF[b] = (int)Fb;
+    Tmax = std::max(Tmax, utts[b].t);
+    Fmax = std::max(Fmax, Fb);
   }
-  if (slot < 0 || slot >= kMaxSlots) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d out of range [0,%d)", slot, kMaxSlots);
-  if (F64 * v->hop * n > 0x3fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch too large");
+  const int T = bucket_t(Tmax), F = bucket_f((int)Fmax), I = v->cfg.inter;
+  if ((int64_t)F * v->hop * n > 0x3fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch too large");
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
-  Slot& s = v->slots[slot];
-  if ((rc = slot_init(v, s))) return rc;
-  const int T = utts[0].t, F = (int)F64, I = v->cfg.inter;
-  // the previous launch on this slot may still be reading the inputs
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
-  const bool rebuild = (s.T != T || s.F != F || s.NB != n || !s.exec);
-  if (rebuild) {
-    if ((rc = build_schedule(v, s, T, F, n))) { slot_release(v, s, false); return rc; }
+  Slot* cur = v->attached[slot];
+  const bool same = cur && cur->exec && cur->kind == 0 && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
+  if (cur && !same) detach(v, slot);
+  if (!same) {
+    bool built = false;
+    if ((rc = acquire_plan(v, 0, T, F, n, &cur, &built))) return rc;
+    cur->in_use = true;
+    v->attached[slot] = cur;
+    evict_idle_plans(v);
   }
+  Slot& s = *cur;
+  s.last_use = ++v->use_clock;
+  // the previous launch on this plan may still be reading the inputs
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  s.st_next = -1;
+  s.h_T = hT;
+  s.h_F = hF;
   if (s.h_cap_t < (size_t)T * n) {
     if (s.h_ids) (void)hipHostFree(s.h_ids);
     PH_HIP(hipHostMalloc((void**)&s.h_ids, (size_t)T * n * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
@@ -1435,22 +1606,31 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
     PH_HIP(hipHostMalloc((void**)&s.h_f2i, (size_t)F * n * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
     s.h_cap_f = (size_t)F * n;
   }
+  if (s.h_cap_lens < (size_t)2 * n) {
+    if (s.h_lens) (void)hipHostFree(s.h_lens);
+    PH_HIP(hipHostMalloc((void**)&s.h_lens, (size_t)2 * n * sizeof(int)), PIPER_HIP_ERR_ALLOC);
+    s.h_cap_lens = (size_t)2 * n;
+  }
   s.h_noise_scale.resize(n);
   s.h_rng.resize(2 * (size_t)n);
   for (int b = 0; b < n; b++) {
     const piper_hip_utterance* u = &utts[b];
-    if (u->noise_mode != PIPER_HIP_NOISE_INJECTED && u->noise_mode != PIPER_HIP_NOISE_DEVICE)
-      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: unknown noise_mode %d", b, u->noise_mode);
+    const int Tb = hT[b], Fb = hF[b];
+    s.h_lens[b] = Tb;
+    s.h_lens[n + b] = Fb;
     s.h_rng[2 * b] = (!u->noise && u->noise_mode == PIPER_HIP_NOISE_DEVICE) ? 1u : 0u;
     s.h_rng[2 * b + 1] = u->seed;
-    memcpy(s.h_ids + (size_t)b * T, u->phoneme_ids, (size_t)T * sizeof(int64_t));
+    memcpy(s.h_ids + (size_t)b * T, u->phoneme_ids, (size_t)Tb * sizeof(int64_t));
+    for (int t = Tb; t < T; t++) s.h_ids[(size_t)b * T + t] = 0;  // rows of the bucket beyond the utterance: any legal id
     int f = 0;  // generate_path: frame f belongs to the phoneme whose cumulative duration covers it
-    for (int t = 0; t < T; t++)
+    for (int t = 0; t < Tb; t++)
       for (int j = 0; j < u->durations[t]; j++) s.h_f2i[(size_t)b * F + f++] = t;
+    for (; f < F; f++) s.h_f2i[(size_t)b * F + f] = 0;
     s.h_noise_scale[b] = u->noise_scale;
+    // noise [I, Fb] → rows of the bucket [I, F]
     if (u->noise)
-      PH_HIP(hipMemcpyAsync(s.noise + (size_t)b * I * F, u->noise, (size_t)I * F * sizeof(float), hipMemcpyHostToDevice, s.stream),
-             PIPER_HIP_ERR_LAUNCH);
+      PH_HIP(hipMemcpy2DAsync(s.noise + (size_t)b * I * F, (size_t)F * sizeof(float), u->noise, (size_t)Fb * sizeof(float), (size_t)Fb * sizeof(float),
+                              (size_t)I, hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
     else if (!s.h_rng[2 * b])
       PH_HIP(hipMemsetAsync(s.noise + (size_t)b * I * F, 0, (size_t)I * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
   }
@@ -1458,32 +1638,9 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   PH_HIP(hipMemcpyAsync(s.noise_scale, s.h_noise_scale.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * n * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * n * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.lensT, s.h_lens, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.lensF, s.h_lens + n, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // noise / scalars come from caller memory
-  if (rebuild) {
-    // one eager pass validates every launch (and sets kernel attributes) before capture
-    if ((rc = run_schedule(s, s.stream, false))) { slot_release(v, s, false); return rc; }
-    hipError_t e = hipStreamSynchronize(s.stream);
-    if (e != hipSuccess) {
-      slot_release(v, s, false);
-      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
-    }
-    PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
-    // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
-    // short kernels gain: factor 1 1.34 → 1.50 ms, factor 8 1.65 → 1.89 ms), so that graph stays a single chain unless
-    // asked otherwise. The bf16 generator's builder decides for itself (s.parallel).
-    rc = run_schedule(s, s.stream, s.parallel);
-    hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
-    if (rc || ce != hipSuccess) {
-      slot_release(v, s, false);
-      if (rc) return rc;
-      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph capture failed: %s", hipGetErrorString(ce));
-    }
-    ce = hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0);
-    if (ce != hipSuccess) {
-      slot_release(v, s, false);
-      PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph instantiate failed: %s", hipGetErrorString(ce));
-    }
-  }
   s.timed = false;
   return slot;
 }
@@ -1493,15 +1650,31 @@ PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_uttera
 }
 
 PH_EXPORT int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot) {
-  if (!v || slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) return 0;
-  return v->slots[slot].NB;
+  const Slot* p = slot_plan(v, slot);
+  return p ? p->NB : 0;
+}
+
+PH_EXPORT int piper_hip_voice_plan_info(const piper_hip_voice* v, int slot, int32_t* bucket_t_out, int32_t* bucket_f_out, int32_t* cached_plans,
+                                        size_t* cached_bytes) {
+  if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  const Slot* p = slot_plan(v, slot);
+  if (bucket_t_out) *bucket_t_out = p ? p->T : 0;
+  if (bucket_f_out) *bucket_f_out = p ? p->F : 0;
+  if (cached_plans) *cached_plans = (int32_t)v->plans.size();
+  if (cached_bytes) {
+    size_t b = 0;
+    for (auto& pl : v->plans) b += pl->arena_bytes;
+    *cached_bytes = b;
+  }
+  return PIPER_HIP_OK;
 }
 
 PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  Slot* p = slot_plan(v, slot);
+  if (!p) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
-  Slot& s = v->slots[slot];
+  Slot& s = *p;
   PH_HIP(hipEventRecord(s.ev0, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipGraphLaunch(s.exec, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventRecord(s.ev1, s.stream), PIPER_HIP_ERR_LAUNCH);
@@ -1511,13 +1684,21 @@ PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
 
 PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
+  Slot* p = slot_plan(v, slot);
+  if (!p) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
-  Slot& s = v->slots[slot];
+  Slot& s = *p;
   if (host_audio) {
-    const int64_t total = s.n_samples * s.NB;  // batch items back to back
+    int64_t total = 0;  // batch items back to back, each at its own true length
+    for (int b = 0; b < s.NB; b++) total += (int64_t)s.h_F[b] * v->hop;
     if (max_samples < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)total);
-    PH_HIP(hipMemcpyAsync(host_audio, s.audio, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
+    int64_t off = 0;
+    for (int b = 0; b < s.NB; b++) {
+      const int64_t nb = (int64_t)s.h_F[b] * v->hop;
+      PH_HIP(hipMemcpyAsync(host_audio + off, s.audio + (int64_t)b * s.n_samples, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, s.stream),
+             PIPER_HIP_ERR_LAUNCH);
+      off += nb;
+    }
   }
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;
@@ -1571,28 +1752,6 @@ int capture_steps(Slot& s, const std::vector<int>& pick, hipGraph_t* g, hipGraph
   return PIPER_HIP_OK;
 }
 
-// generator-only schedule for a window of `Fc` frames (cached per width)
-int generator_slot(piper_hip_voice* v, int Fc, Slot** out) {
-  auto it = v->gen_slots.find(Fc);
-  if (it != v->gen_slots.end() && it->second->exec) { *out = it->second.get(); return PIPER_HIP_OK; }
-  if (v->gen_slots.size() >= 6) {  // first / interior / last window widths of a couple of chunk sizes; beyond that start over
-    PH_HIP(hipDeviceSynchronize(), PIPER_HIP_ERR_LAUNCH);
-    for (auto& kv : v->gen_slots) slot_release(v, *kv.second, true);
-    v->gen_slots.clear();
-  }
-  std::unique_ptr<Slot> gs(new Slot());
-  int rc = slot_init(v, *gs);
-  if (rc) return rc;
-  if ((rc = build_schedule(v, *gs, 0, Fc, 1, true))) { slot_release(v, *gs, true); return rc; }
-  std::vector<int> all;
-  for (int i = 0; i < (int)gs->steps.size(); i++)
-    if (gs->steps[i].kind == Step::LAUNCH) all.push_back(i);
-  if ((rc = capture_steps(*gs, all, &gs->graph, &gs->exec))) { slot_release(v, *gs, true); return rc; }
-  *out = gs.get();
-  v->gen_slots[Fc] = std::move(gs);
-  return PIPER_HIP_OK;
-}
-
 }  // namespace
 
 PH_EXPORT int piper_hip_voice_receptive_field(const piper_hip_voice* v) { return v ? generator_halo_frames(v->cfg) : -1; }
@@ -1601,7 +1760,7 @@ PH_EXPORT int piper_hip_voice_stream_begin(piper_hip_voice* v, const piper_hip_u
   if (chunk_frames < 1) PH_FAIL(PIPER_HIP_ERR_ARG, "stream_begin: chunk_frames must be >= 1");
   int rc = piper_hip_voice_prepare(v, u, slot);
   if (rc < 0) return rc;
-  Slot& s = v->slots[slot];
+  Slot& s = *v->attached[slot];
   if (!s.front_exec) {  // encoder + flow as their own graph (everything before the generator's first launch)
     std::vector<int> front;
     for (int i = 0; i < (int)s.steps.size(); i++) {
@@ -1615,34 +1774,46 @@ PH_EXPORT int piper_hip_voice_stream_begin(piper_hip_voice* v, const piper_hip_u
   s.st_chunk = chunk_frames;
   s.st_halo = generator_halo_frames(v->cfg);
   s.st_next = 0;
-  return (int)ceil_div(s.F, chunk_frames);
+  return (int)ceil_div(s.h_F[0], chunk_frames);
 }
 
 PH_EXPORT int piper_hip_voice_stream_next(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples, int64_t* n_samples) {
   if (!v || !n_samples) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
-  if (slot < 0 || slot >= kMaxSlots || v->slots[slot].st_next < 0) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no stream in progress", slot);
-  Slot& s = v->slots[slot];
+  Slot* sp = slot_plan(v, slot);
+  if (!sp || sp->st_next < 0) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no stream in progress", slot);
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  Slot& s = *sp;
+  const int Ftrue = s.h_F[0];
   *n_samples = 0;
-  if (s.st_next >= s.F) return PIPER_HIP_OK;  // end of stream
-  const int f0 = s.st_next, f1 = std::min(s.F, f0 + s.st_chunk);
+  if (s.st_next >= Ftrue) return PIPER_HIP_OK;  // end of stream
+  const int f0 = s.st_next, f1 = std::min(Ftrue, f0 + s.st_chunk);
   // window = chunk + receptive field, clamped to the utterance: at the utterance's own ends the convs' zero padding is
   // then the same zero padding the whole-utterance run sees, inside it the halo frames are recomputed and dropped
-  const int a = std::max(0, f0 - s.st_halo), b = std::min(s.F, f1 + s.st_halo);
+  const int a = std::max(0, f0 - s.st_halo), b = std::min(Ftrue, f1 + s.st_halo);
   const int Fc = b - a;
   const int64_t want = (int64_t)(f1 - f0) * v->hop;
   if (host_audio && max_samples < want) PH_FAIL(PIPER_HIP_ERR_SHAPE, "stream_next: buffer holds %lld < %lld samples", (long long)max_samples, (long long)want);
+  // generator-only plan of the window's bucket (first / interior / last windows of a stream usually share one)
   Slot* gs = nullptr;
-  int rc = generator_slot(v, Fc, &gs);
+  bool built = false;
+  int rc = acquire_plan(v, 1, 0, bucket_f(Fc), 1, &gs, &built);
   if (rc) return rc;
+  gs->in_use = true;
+  gs->last_use = ++v->use_clock;
   const int I = v->cfg.inter;
-  PH_HIP(hipStreamWaitEvent(gs->stream, s.ev1, 0), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipMemcpy2DAsync(gs->zin, (size_t)Fc * sizeof(float), s.z_out + a, (size_t)s.F * sizeof(float), (size_t)Fc * sizeof(float), (size_t)I,
-                          hipMemcpyDeviceToDevice, gs->stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipGraphLaunch(gs->exec, gs->stream), PIPER_HIP_ERR_LAUNCH);
-  if (host_audio)
-    PH_HIP(hipMemcpyAsync(host_audio, gs->audio + (int64_t)(f0 - a) * v->hop, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, gs->stream),
-           PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipStreamSynchronize(gs->stream), PIPER_HIP_ERR_LAUNCH);
+  hipError_t e = hipStreamWaitEvent(gs->stream, s.ev1, 0);
+  int lens[2] = {0, Fc};
+  if (e == hipSuccess) e = hipMemcpyAsync(gs->lensF, &lens[1], sizeof(int), hipMemcpyHostToDevice, gs->stream);
+  if (e == hipSuccess)
+    e = hipMemcpy2DAsync(gs->zin, (size_t)gs->F * sizeof(float), s.z_out + a, (size_t)s.F * sizeof(float), (size_t)Fc * sizeof(float), (size_t)I,
+                         hipMemcpyDeviceToDevice, gs->stream);
+  if (e == hipSuccess) e = hipGraphLaunch(gs->exec, gs->stream);
+  if (e == hipSuccess && host_audio)
+    e = hipMemcpyAsync(host_audio, gs->audio + (int64_t)(f0 - a) * v->hop, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, gs->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(gs->stream);
+  gs->in_use = false;
+  evict_idle_plans(v);
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "stream_next: %s", hipGetErrorString(e));
   *n_samples = want;
   s.st_next = f1;
   return PIPER_HIP_OK;
@@ -1654,30 +1825,43 @@ PH_EXPORT int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utt
   if (rc < 0) return rc;
   if ((rc = piper_hip_voice_launch(v, 0))) return rc;
   if ((rc = piper_hip_voice_collect(v, 0, host_audio, max_samples))) return rc;
-  if (n_samples) *n_samples = v->slots[0].n_samples;
+  if (n_samples) *n_samples = (int64_t)v->attached[0]->h_F[0] * v->hop;
   return PIPER_HIP_OK;
 }
 
 PH_EXPORT int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name, float* host, size_t max_floats,
                                   size_t* n_floats) {
   if (!v || !name) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
-  Slot& s = v->slots[slot];
+  Slot* sp = slot_plan(v, slot);
+  if (!sp) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot& s = *sp;
   auto it = s.taps.find(name);
   if (it == s.taps.end()) PH_FAIL(PIPER_HIP_ERR_ARG, "unknown tap '%s'", name);
-  if (n_floats) *n_floats = it->second.second;
+  const Slot::Tap& t = it->second;
+  // items back to back, each compacted to its true length: [C][len_b]
+  size_t total = 0;
+  for (int b = 0; b < s.NB; b++) total += (size_t)t.C * (size_t)(t.unit == 0 ? s.h_T[b] : s.h_F[b]);
+  if (n_floats) *n_floats = total;
   if (host) {
-    if (max_floats < it->second.second) PH_FAIL(PIPER_HIP_ERR_SHAPE, "tap buffer too small");
+    if (max_floats < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "tap buffer too small");
+    PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
     PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
-    PH_HIP(hipMemcpy(host, it->second.first, it->second.second * sizeof(float), hipMemcpyDeviceToHost), PIPER_HIP_ERR_LAUNCH);
+    size_t off = 0;
+    for (int b = 0; b < s.NB; b++) {
+      const size_t len = (size_t)(t.unit == 0 ? s.h_T[b] : s.h_F[b]);
+      PH_HIP(hipMemcpy2D(host + off, len * sizeof(float), t.p + (size_t)b * t.batch_stride, (size_t)t.row * sizeof(float), len * sizeof(float),
+                         (size_t)t.C, hipMemcpyDeviceToHost), PIPER_HIP_ERR_LAUNCH);
+      off += (size_t)t.C * len;
+    }
   }
   return PIPER_HIP_OK;
 }
 
 PH_EXPORT int piper_hip_voice_last_gpu_ms(piper_hip_voice* v, int slot, double* ms) {
   if (!v || !ms) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].timed) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no timed launch", slot);
-  Slot& s = v->slots[slot];
+  Slot* sp = slot_plan(v, slot);
+  if (!sp || !sp->timed) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d has no timed launch", slot);
+  Slot& s = *sp;
   PH_HIP(hipEventSynchronize(s.ev1), PIPER_HIP_ERR_LAUNCH);
   float f = 0;
   PH_HIP(hipEventElapsedTime(&f, s.ev0, s.ev1), PIPER_HIP_ERR_LAUNCH);
@@ -1686,16 +1870,17 @@ PH_EXPORT int piper_hip_voice_last_gpu_ms(piper_hip_voice* v, int slot, double* 
 }
 
 PH_EXPORT piper_hip_stream piper_hip_voice_slot_stream(piper_hip_voice* v, int slot) {
-  if (!v || slot < 0 || slot >= kMaxSlots) return nullptr;
-  return (piper_hip_stream)v->slots[slot].stream;
+  Slot* sp = slot_plan(v, slot);
+  return sp ? (piper_hip_stream)sp->stream : nullptr;
 }
 
 PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, piper_hip_kernel_stat* out, int max_entries,
                                       int* n_entries) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot* sp = slot_plan(v, slot);
+  if (!sp) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   if (iters < 1) iters = 1;
-  Slot& s = v->slots[slot];
+  Slot& s = *sp;
   const int n = (int)s.steps.size();
   if (n_entries) *n_entries = n;
   if (!out) return PIPER_HIP_OK;
@@ -1759,9 +1944,10 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
 PH_EXPORT int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const char* name_filter, int iters, double* avg_launch_us,
                                           int* n_launches, double* flops, double* bytes) {
   if (!v || !name_filter) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
-  if (slot < 0 || slot >= kMaxSlots || !v->slots[slot].exec) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  Slot* sp = slot_plan(v, slot);
+  if (!sp) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   if (iters < 1) iters = 1;
-  Slot& s = v->slots[slot];
+  Slot& s = *sp;
   std::vector<int> pick;
   double fl = 0, by = 0;
   for (int i = 0; i < (int)s.steps.size(); i++)

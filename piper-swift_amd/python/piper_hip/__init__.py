@@ -197,6 +197,8 @@ _PROTOS = {
     "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
     "piper_hip_voice_prepare_batch": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
     "piper_hip_voice_batch_size": (C.c_int, [c_vp, C.c_int]),
+    "piper_hip_voice_plan_info": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_size_t)]),
     "piper_hip_voice_launch": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_collect": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64]),
     "piper_hip_voice_synthesize": (C.c_int, [c_vp, C.POINTER(Utterance), c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
@@ -748,20 +750,26 @@ class HipRuntime:
             yield buf[:got.value].copy()
 
     def prepare_batch(self, slot, utterances, noiseScale=0.667):
-        """utterances: list of (phonemeIDs, durations, noise-or-None), all with the same T and the same Σ durations."""
+        """utterances: list of (phonemeIDs, durations, noise-or-None); lengths may differ (ragged batch, one bucket)."""
         n = len(utterances)
         arr = (Utterance * n)()
         keep = []
+        total = 0
         for i, (ids, dur, noise) in enumerate(utterances):
             u, k = self._utt(ids, dur, noise, noiseScale)
             arr[i] = u
             keep.append(k)
-        ns = int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(arr[0])))
-        self._keep[slot] = (keep, ns * n)
+            total += int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(arr[i])))
+        self._keep[slot] = (keep, total)
         rc = self.lib.piper_hip_voice_prepare_batch(self.voice, arr, n, slot)
         if rc < 0:
             _check(rc)
         return rc
+
+    def plan_info(self, slot):
+        bt, bf, n, by = C.c_int32(), C.c_int32(), C.c_int32(), C.c_size_t()
+        _check(self.lib.piper_hip_voice_plan_info(self.voice, slot, C.byref(bt), C.byref(bf), C.byref(n), C.byref(by)))
+        return dict(bucket_t=bt.value, bucket_f=bf.value, cached_plans=n.value, cached_bytes=by.value)
 
     def launch(self, slot):
         _check(self.lib.piper_hip_voice_launch(self.voice, slot))
