@@ -576,6 +576,220 @@ int launch_att_mfma(hipStream_t s, const float* q, const float* k, const float* 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: the same MFMA formulation with K and V staged through LDS in full rows.
+// r2d measurement: the register-fragment kernel above spends its time in the texture path — every fragment load is a
+// wave-instruction that touches 4 × 64-byte segments (16 keys × 4 channels), 68 of them per wave, and the block's 8 waves
+// share one address unit — 10 µs per head at T = 112 for 0.03 GFLOP. Here a K (then V) tile of 128 keys × all D channels is
+// fetched ONCE per block with 16-byte loads along the key axis (rows of 512 contiguous bytes), written to LDS with row
+// strides chosen so that both fragment shapes read conflict-free (K rows ≡ 16 floats mod 32: B[k = channel][n = key];
+// V rows ≡ 2 mod 32: A[m = channel][k = key]), and all fragments come from LDS. V's first tile is requested before the score
+// phase and parked in registers, so the softmax hides its latency. Needs T % 4 == 0 (16-byte rows; every bucketed plan has
+// T % 16 == 0) and T ≤ 1024 (score strip + tiles in 160 KiB); other shapes take the register-fragment kernel.
+constexpr int kTK = 128;               // keys per staged tile
+constexpr int kLdK = kTK + 16;         // ≡ 16 (mod 32)
+constexpr int kLdV = kTK + 2;          // ≡ 2 (mod 32)
+
+template <int D>
+__global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                          const float* __restrict__ v, const float* __restrict__ ek,
+                                                                          const float* __restrict__ ev, float* __restrict__ out, int T,
+                                                                          int w, int64_t in_batch_stride, int64_t out_batch_stride,
+                                                                          const int* __restrict__ len_ptr, int Tp) {
+  constexpr int RV = 16, NS = D / 4, NCT = D / 16;
+  constexpr int NT = 64 * kAttWaves;                 // threads
+  constexpr int F4 = D * (kTK / 4);                  // float4 slots of a staged tile
+  constexpr int SLOTS = (F4 + NT - 1) / NT;          // per thread (6 for D = 96)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                       // [D][kLdK] (K) or [D][kLdV] (V)
+  float* sc = tile + D * kLdK;              // [16][Tp]
+  float* qs = sc + RV * Tp;                 // [D][16]  A fragments of the q strip
+  float* qe = qs + D * 16;                  // [16][17]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.x * RV, h = blockIdx.y, n = blockIdx.z;
+  const int Tv = len_ptr ? min(len_ptr[n], T) : T;
+  if (i0 >= Tv) return;
+  const int W = 2 * w + 1;
+  const int64_t hoff = (int64_t)n * in_batch_stride + (int64_t)h * D * T;
+  const float* qb = q + hoff;
+  const float* kb = k + hoff;
+  const float* vb = v + hoff;
+  const float scale = sqrtf((float)D);
+  const int ntile = (Tv + kTK - 1) / kTK;
+
+  float4 stg[SLOTS];
+  // tile `t0` of `src` → registers: slot e = tid + NT·i ↔ (row = e / 32, 16-byte column = e % 32); rows are T floats apart and
+  // T % 4 == 0, so every load is aligned; columns past the row end are clamped (their keys are masked at use)
+  auto fetch = [&](const float* src, int t0) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+      const int e = tid + NT * i;
+      const int row = min(e >> 5, D - 1), c4 = e & 31;
+      const int col = min(t0 + 4 * c4, T - 4);
+      stg[i] = *(const float4*)(src + (int64_t)row * T + col);
+    }
+  };
+  auto commit = [&](int ld, int t0) {  // registers → LDS tile with row stride ld (8-byte stores: ld is even)
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+      const int e = tid + NT * i;
+      const int row = e >> 5, c4 = e & 31;
+      if (row < D) {
+        float4 val = stg[i];
+        if (t0 + 4 * c4 > T - 4) val = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // clamped load: not this tile's columns
+        float2* dst = (float2*)(tile + row * ld + 4 * c4);
+        dst[0] = make_float2(val.x, val.y);
+        dst[1] = make_float2(val.z, val.w);
+      }
+    }
+  };
+
+  // ---- 0. q strip → LDS (scaled: Div of the graph), first K tile in flight
+  fetch(kb, 0);
+  for (int e = tid; e < D * 16; e += NT) {
+    const int c = e >> 4, i = e & 15;
+    const bool ok = i0 + i < Tv;
+    const float qv = qb[(int64_t)c * T + min(i0 + i, Tv - 1)];
+    qs[c * 16 + i] = ok ? qv / scale : 0.0f;
+  }
+  // relative-key logits: wave 7 straight from global (E_k is tiny), while the others wait for the K tile
+  float ekf[NS];
+  if (wave == kAttWaves - 1) {
+    const int mc = min(r16, W - 1);
+#pragma unroll
+    for (int s = 0; s < NS; s++) ekf[s] = ek[mc * D + 4 * s + kq];
+  }
+  commit(kLdK, 0);
+  __syncthreads();
+  if (wave == kAttWaves - 1) {
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NS; s += 2) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(4 * s + kq) * 16 + r16], r16 < W ? ekf[s] : 0.0f, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(4 * (s + 1) + kq) * 16 + r16], r16 < W ? ekf[s + 1] : 0.0f, a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) qe[(4 * kq + r) * 17 + r16] = a0[r] + a1[r];
+  }
+
+  // ---- 1. scores, one staged K tile (8 key tiles of 16, one per wave) at a time
+  for (int t = 0; t < ntile; t++) {
+    const int t0 = t * kTK;
+    if (t + 1 < ntile) fetch(kb, t0 + kTK);  // next K tile in flight
+    else fetch(vb, 0);                       // … or V's first tile: lands under the softmax
+    const int j0 = t0 + wave * 16;
+    if (j0 < Tv) {  // wave-uniform
+      const bool col_ok = j0 + r16 < Tv;
+      f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int s = 0; s < NS; s += 2) {
+        const float b0 = tile[(4 * s + kq) * kLdK + wave * 16 + r16], b1 = tile[(4 * (s + 1) + kq) * kLdK + wave * 16 + r16];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(4 * s + kq) * 16 + r16], col_ok ? b0 : 0.0f, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qs[(4 * (s + 1) + kq) * 16 + r16], col_ok ? b1 : 0.0f, a1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) sc[(4 * kq + r) * Tp + j0 + r16] = a0[r] + a1[r];
+    }
+    __syncthreads();  // every wave is done with this K tile
+    if (t + 1 < ntile) {
+      commit(kLdK, t0 + kTK);
+      __syncthreads();
+    }
+  }
+
+  // ---- 2. softmax (softmax.metal:13-41), relative-key logits added on the way in; V tile 0 sits in registers meanwhile
+  for (int r = wave; r < RV; r += kAttWaves) {
+    const int ia = i0 + r;
+    if (ia >= Tv) break;  // wave-uniform
+    float* row = sc + r * Tp;
+    const float* qr = qe + r * 17;
+    float m = -INFINITY;
+    for (int j = lane; j < Tv; j += 64) {
+      const int delta = j - ia;
+      float sv = row[j];
+      if (delta >= -w && delta <= w) sv += qr[delta + w];
+      row[j] = sv;
+      m = fmaxf(m, sv);
+    }
+    m = wave_max(m);
+    float sum = 0.0f;
+    for (int j = lane; j < Tv; j += 64) {
+      const float e = expf(row[j] - m);
+      row[j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < Tv; j += 64) row[j] *= inv;
+  }
+  commit(kLdV, 0);
+  __syncthreads();
+
+  // ---- 3. P·V over the staged V tiles (waves 0 … NCT−1: one 16-channel tile each), then the relative-value steps
+  const bool pi_ok = i0 + r16 < Tv;
+  const float* prow = sc + r16 * Tp;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
+  float arel[4];
+  if (wave < NCT) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + wave * 16 + r16];
+  }
+  for (int t = 0; t < ntile; t++) {
+    const int t0 = t * kTK;
+    if (t + 1 < ntile) fetch(vb, t0 + kTK);
+    if (wave < NCT) {
+      const float* vrow = tile + (wave * 16 + r16) * kLdV;
+      const int nst = min(kTK, Tv - t0 + 3) >> 2;  // steps of 4 keys in this tile
+      for (int s = 0; s < nst; s += 2) {
+        const int j = t0 + 4 * s + kq;
+        const bool ok = j < Tv, ok2 = j + 4 < Tv && s + 1 < nst;
+        const float a0v = vrow[4 * s + kq], a1v = vrow[min(4 * (s + 1) + kq, kTK - 1)];
+        const float b0v = prow[min(j, Tv - 1)], b1v = prow[min(j + 4, Tv - 1)];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? a0v : 0.0f, (ok && pi_ok) ? b0v : 0.0f, acc, 0, 0, 0);
+        accb = __builtin_amdgcn_mfma_f32_16x16x4f32(ok2 ? a1v : 0.0f, (ok2 && pi_ok) ? b1v : 0.0f, accb, 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntile) {
+      __syncthreads();
+      commit(kLdV, t0 + kTK);
+      __syncthreads();
+    }
+  }
+  if (wave < NCT) {
+    const int ia = i0 + r16;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int mrel = 4 * s + kq;
+      const bool mok = mrel < W;
+      const int j = ia + mrel - w;
+      const bool jok = mok && pi_ok && j >= 0 && j < Tv;
+      const float b = prow[jok ? j : 0];
+      if (4 * s < W) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? arel[s] : 0.0f, jok ? b : 0.0f, acc, 0, 0, 0);
+    }
+    float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * D * T;
+    if (pi_ok) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) ob[(int64_t)(wave * 16 + 4 * kq + r) * T + i0 + r16] = acc[r] + accb[r];
+    }
+  }
+}
+
+template <int D>
+int launch_att_lds(hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, float* out, int N, int H,
+                   int T, int w, int64_t in_bs, int64_t out_bs, const int* len_ptr) {
+  const int Tp = ((T + 31) / 32) * 32 + 2;
+  const size_t lds = ((size_t)D * kLdK + (size_t)16 * Tp + (size_t)D * 16 + 16 * 17) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  static bool raised[ph::kMaxDevices] = {};
+  if (lds > 64 * 1024 && ph::lds_optin_needed(raised))
+    (void)hipFuncSetAttribute((const void*)rel_attention_lds_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  dim3 grid((unsigned)ph::ceil_div(T, 16), (unsigned)H, (unsigned)N);
+  hipLaunchKernelGGL((rel_attention_lds_kernel<D>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp);
+  return 0;
+}
+
 template <int D>
 int launch_att_block(hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, const float* wo16,
                      const float* bo, const float* xres, const float* gamma, const float* beta, float* out, int N, int H, int T, int w,
@@ -600,6 +814,15 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
                          int64_t out_batch_stride, const int* len_ptr) {
   if (N <= 0 || T <= 0) return PIPER_HIP_OK;
   static const bool no_mfma = getenv("PIPER_HIP_ATT_SCALAR") != nullptr;  // A/B switch: the round-1 scalar kernel
+  static const bool no_lds = getenv("PIPER_HIP_ATT_NO_LDS") != nullptr;  // A/B switch: register-fragment MFMA kernel
+  if (!no_mfma && !no_lds && d == 96 && w >= 0 && 2 * w + 1 <= 16 && H <= 65535 && N <= 65535 && T <= 1024 && T >= 4 && (T & 3) == 0 &&
+      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && (in_batch_stride & 3) == 0) {
+    if (launch_att_lds<96>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr) == 0) {
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention (lds) launch failed: %s", hipGetErrorString(e));
+      return PIPER_HIP_OK;
+    }
+  }
   if (!no_mfma && d == 96 && w >= 0 && 2 * w + 1 <= 16 && H <= 65535 && N <= 65535 && T <= 4096) {
     int rc = T <= 2048 ? launch_att_mfma<96, 16>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr)
                        : launch_att_mfma<96, 8>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr);
@@ -649,11 +872,16 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;
 }
+// Measured at T = 112 (r2d): the fused launch takes 29 µs against 27 µs for the three launches it replaces — the heads'
+// fragment-shaped loads keep the texture path busy — so the VOICE schedule uses it only on request (PIPER_HIP_ATT_BLOCK=1);
+// the op-level entry point always runs it.
+bool attention_block_wanted() {
+  static const bool on = getenv("PIPER_HIP_ATT_BLOCK") != nullptr && getenv("PIPER_HIP_ATT_SCALAR") == nullptr;
+  return on;
+}
+
 bool attention_block_eligible(int H, int d, int w, int T) {
-  // A/B switch. Measured at T = 112 (r2d): the fused launch takes 29 µs against 27 µs for the three launches it replaces —
-  // the heads' fragment-shaped loads keep the texture path busy — so it is opt-in (PIPER_HIP_ATT_BLOCK=1) until it wins.
-  static const bool off = getenv("PIPER_HIP_ATT_BLOCK") == nullptr || getenv("PIPER_HIP_ATT_SCALAR") != nullptr;
-  if (off || d != 96 || H * d > 256 || (H * d) % 32 || 2 * w + 1 > 16 || w < 0 || T > 2048 || T < 1) return false;
+  if (d != 96 || H * d > 256 || (H * d) % 32 || 2 * w + 1 > 16 || w < 0 || T > 2048 || T < 1) return false;
   const int Tp = ((T + 31) / 32) * 32 + 2;
   return ((size_t)2 * 16 * Tp + 2 * 16 * 17 + (size_t)H * d * 16 + kAttWaves * 16) * sizeof(float) <= 160 * 1024;
 }

@@ -9,6 +9,7 @@ enum Prologue : int {
   PRO_NONE = 0,
   PRO_LRELU = 1,       // x = lrelu(x, alpha)
   PRO_AVG3_LRELU = 2,  // x = lrelu(((x + x2) + x3) / 3, alpha)   (HiFi-GAN MRF mean folded into the consumer)
+  PRO_LN = 3,          // x = ((x − mean_t) / sd_t)·ln_gamma[c] + ln_beta[c]: channel LayerNorm folded into the consumer (K ∈ {1,3})
 };
 
 // output transform / routing applied to the accumulator tile
@@ -61,6 +62,19 @@ struct ConvArgs {
   // don't-care values (never read unmasked by anything downstream).
   const int* len_ptr = nullptr;
   int len_mul = 1;
+  // LayerNorm across a kernel boundary without a kernel of its own (GraphExecutor.swift:2071-2125: ReduceMean / Sub / Pow /
+  // ReduceMean / Add / Sqrt / Div / Mul / Add). PRODUCER (EPI_STORE with stats_out): besides y = res + conv it writes, per
+  // 16-row slot and column, the partial sums Σ y and Σ y² of its rows → stats_out [N][ceil(Cout/16)][y_len][2] (32-row tiles
+  // fill the even slot and zero the odd one, so the consumer never needs to know the producer's tile size; fixed slots ⇒
+  // deterministic). CONSUMER (PRO_LN): adds the slots of a column in order, mean = Σ/C, var = Σ²/C − mean² (≥ 0), and
+  // normalises its B operand on load; the waves of row tile 0 also write the normalised tensor to ln_out (the residual
+  // operand of the next Add, and the "enc_out" tap).
+  float* stats_out = nullptr;
+  const float* ln_stats = nullptr;
+  const float* ln_gamma = nullptr;
+  const float* ln_beta = nullptr;
+  float* ln_out = nullptr;
+  float ln_eps = 1e-5f;
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv

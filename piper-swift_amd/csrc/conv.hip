@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void convt_direct_kernel(const float* __res
 bool try_launch_tile(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
   static const int mode = [] { const char* e = getenv("PIPER_HIP_TILE"); return e ? atoi(e) : -1; }();  // A/B switch: 0 off, 1 force
   if (mode == 0) return false;
-  if (a.gate || a.Lout < 2048) return false;
+  if (a.gate || a.Lout < 2048 || a.prologue == PRO_LN || a.stats_out) return false;
   const int mtiles = (int)ceil_div(a.Cout, 32);
   int MT = mtiles >= 4 ? 4 : (mtiles >= 2 ? 2 : 1);
   int NTW = MT == 4 ? 1 : 2;
@@ -266,6 +266,10 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   if (a.N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: batch %d too large", a.N);
   if (!k_supported(a.K)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: no streaming kernel for %d taps", a.K);
   if (a.gate && (a.Cout % 64)) PH_FAIL(PIPER_HIP_ERR_SHAPE, "gated conv needs Cout %% 64 == 0 (got %d)", a.Cout);
+  if (a.prologue == PRO_LN && (!a.ln_stats || !a.ln_gamma || !a.ln_beta || a.in_ch_sign != 1 || a.in_ch_base != 0 || a.dil < 1 || (a.K != 1 && a.K != 3)))
+    PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: PRO_LN needs statistics, gamma, beta, the identity channel map and K in {1, 3}");
+  if (a.stats_out && (a.epilogue != EPI_STORE || a.gate || a.out_ch_sign != 1 || a.out_ch_base != 0))
+    PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: stats_out needs the plain store epilogue");
   if (a.x_batch_stride * 4 > 0x7fffffffLL) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: input larger than 2 GiB per batch item");
   if (try_launch_tile(ctx, s, a)) {
     hipError_t e = hipGetLastError();

@@ -285,9 +285,32 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       }
       // D groups form a register ring: D−1 groups of loads are in flight while one group feeds the matrix pipe.  With
       // ~1–2 waves per SIMD (all a short utterance offers) this is what covers the 0.3–2 µs load latency.
-      constexpr int regs_per_group = S * (NA + NX * NT);
+      // PRO_LN: statistics of this lane's columns (one per tap and time tile), from the producer's per-slot partial sums
+      float lnm[PRO == PRO_LN ? K : 1][NT], lns[PRO == PRO_LN ? K : 1][NT];
+      if constexpr (PRO == PRO_LN) {
+        const int parts = (p.Cin + 15) >> 4;
+        const float* sb = p.ln_stats + (int64_t)n * parts * p.Lin * 2;
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+          for (int nt = 0; nt < NT; nt++) {
+            const int col = min(max(tb + k * p.dil + TM * nt + j, 0), p.Lin - 1);
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int q = 0; q < parts; q++) {  // fixed order
+              const float2 pr = *(const float2*)(sb + ((int64_t)q * p.Lin + col) * 2);
+              s1 += pr.x;
+              s2 += pr.y;
+            }
+            const float mean = s1 / (float)p.Cin;
+            const float var = fmaxf(s2 / (float)p.Cin - mean * mean, 0.0f);
+            lnm[k][nt] = mean;
+            lns[k][nt] = sqrtf(var + p.ln_eps);
+          }
+      }
+      constexpr int regs_per_group = S * (NA + NX * NT) + (PRO == PRO_LN ? 2 * G : 0);
       constexpr int D = BT > 256 ? 2 : (regs_per_group * 4 <= 112 ? 4 : (regs_per_group * 3 <= 132 ? 3 : 2));
       float av[D][NA][S], bv[D][NX][S][NT];
+      float lng[PRO == PRO_LN ? D : 1][G], lnb[PRO == PRO_LN ? D : 1][G];  // gamma / beta of this lane's channel per channel unit
       auto fetch = [&](auto slot_tag, const int g) {
         constexpr int sl = decltype(slot_tag)::value;
 #pragma unroll
@@ -295,6 +318,11 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           const int cp = g * G + gi;
           const int cpc = cp < ncp ? cp : ncp - 1;  // padded steps carry zero weights; keep their rows legal
           const int rowbase = (p.in_ch_base + p.in_ch_sign * CPS * cpc + row_adj) * p.Lin + tb;
+          if constexpr (PRO == PRO_LN) {
+            const int ch = min(CPS * cpc + kk, p.Cin - 1);
+            lng[sl][gi] = p.ln_gamma[ch];
+            lnb[sl][gi] = p.ln_beta[ch];
+          }
 #pragma unroll
           for (int k = 0; k < K; k++) {
             const int st = gi * K + k;
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           }
         }
       };
-      auto compute = [&](auto slot_tag) {
+      auto compute = [&](auto slot_tag, const int g) {
         constexpr int sl = decltype(slot_tag)::value;
 #pragma unroll
         for (int st = 0; st < S; st++) {
@@ -322,7 +350,14 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           for (int nt = 0; nt < NT; nt++) {
             float v = bv[sl][0][st][nt];
             if constexpr (NX == 3) v = ((v + bv[sl][1][st][nt]) + bv[sl][2][st][nt]) / 3.0f;
-            if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
+            if constexpr (PRO == PRO_LN) {
+              v = ((v - lnm[k][nt]) / lns[k][nt]) * lng[sl][st / K] + lnb[sl][st / K];
+              // the row-tile-0 waves materialise the normalised tensor once (centre tap = the column itself)
+              if (mt == 0 && p.ln_out && k * p.dil == p.padL) {
+                const int ch = CPS * (g * G + st / K) + kk, col = t0 + TM * nt + j;
+                if (ch < p.Cin && col < p.Lin) (p.ln_out + (int64_t)n * p.x_batch_stride)[ch * p.Lin + col] = v;
+              }
+            } else if constexpr (PRO != PRO_NONE) v = lrelu(v, p.alpha);
             if constexpr (EDGE) v = ((okbits >> (k * NT + nt)) & 1ull) ? v : 0.0f;
             acc[0][nt] = mfma_t<TM>(av[sl][0][st], v, acc[0][nt]);
             if constexpr (GATE) acc[1][nt] = mfma_t<TM>(av[sl][1][st], v, acc[1][nt]);
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           static_for<D>([&](auto d) {
             const int gg = g + d.value;
             fetch(std::integral_constant<int, (d.value + D - 1) % D>{}, min(gg + D - 1, g_last));
-            if (gg < g_end) compute(d);
+            if (gg < g_end) compute(d, gg);
           });
         }
       }
@@ -384,12 +419,37 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       EpiIn e[NR];
 #pragma unroll
       for (int r = 0; r < NR; r++) e[r] = epi_load<MODE>(p, n, min(mt * TM + acc_row_t<TM>(r, lane), rows_out - 1), colc);
+      float ps1 = 0.0f, ps2 = 0.0f;
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         const int row = mt * TM + acc_row_t<TM>(r, lane);
         float v = acc[0][nt][r];
         if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
-        if (col < p.Lout && row < rows_out) epi_finish<MODE>(p, n, row, col, v, e[r]);
+        if (col < p.Lout && row < rows_out) {
+          epi_finish<MODE>(p, n, row, col, v, e[r]);
+          if constexpr (MODE == EPI_STORE) {
+            const float val = p.res ? v + e[r].a : v;  // exactly what epi_finish stored
+            ps1 += val;
+            ps2 += val * val;
+          }
+        }
+      }
+      if constexpr (MODE == EPI_STORE && !GATE) {
+        if (p.stats_out) {  // wave-uniform: partial LayerNorm sums of this tile's rows per column (see ConvArgs)
+          ps1 += __shfl_xor(ps1, 32, 64);
+          ps2 += __shfl_xor(ps2, 32, 64);
+          if constexpr (TM == 16) {
+            ps1 += __shfl_xor(ps1, 16, 64);
+            ps2 += __shfl_xor(ps2, 16, 64);
+          }
+          if (lane < TM && col < p.Lout) {
+            const int parts = (p.Cout + 15) >> 4;
+            float* sb = p.stats_out + (int64_t)n * parts * p.y_len * 2;
+            const int slot = TM == 16 ? mt : 2 * mt;
+            *(float2*)(sb + ((int64_t)slot * p.y_len + col) * 2) = make_float2(ps1, ps2);
+            if (TM == 32 && slot + 1 < parts) *(float2*)(sb + ((int64_t)(slot + 1) * p.y_len + col) * 2) = make_float2(0.0f, 0.0f);
+          }
+        }
       }
     }
   };
@@ -632,6 +692,9 @@ bool launch_k(hipStream_t s, const ConvArgs& a, int NT, int BT, int nchunks, int
     case PRO_LRELU: return launch_shape<K, false, PRO_LRELU, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
     case PRO_AVG3_LRELU:
       if constexpr (K == 2 || K == 1) return launch_shape<K, false, PRO_AVG3_LRELU, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
+      return false;
+    case PRO_LN:
+      if constexpr (K == 1 || K == 3) return launch_shape<K, false, PRO_LN, TM>(s, a, NT, BT, nchunks, mtiles, ks_log2, ngroups, grid, lds);
       return false;
   }
   return false;

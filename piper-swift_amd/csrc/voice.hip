@@ -30,6 +30,7 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
                          int64_t out_batch_stride, const int* len_ptr);
 bool attention_block_eligible(int H, int d, int w, int T);
+bool attention_block_wanted();
 int launch_attention_block(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev,
                            const float* wo16, const float* bo, const float* xres, const float* gamma, const float* beta, float* out, int N,
                            int H, int d, int T, int w, int64_t in_batch_stride, int64_t x_batch_stride, const int* len_ptr, int o_nsteps,
@@ -738,7 +739,10 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   // voice at factor 8 (48 vs 46 µs per merged launch). Threshold on the launch's FLOPs; PIPER_HIP_PIPE_MIN_GFLOP overrides.
   static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
   static const double pipe_min_flops = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
-  auto pipe_pays = [&](double launch_flops) { return !no_pipe && launch_flops >= pipe_min_flops; };
+  // r2f (factor 64): as a single-conv launch it also loses at 32 / 64 channels (135 vs 114 µs, 105 vs 100 µs: one chunk per
+  // tile leaves nothing to pipeline, and 2 blocks per CU hide less than the window kernel's 4) and wins for ConvTranspose
+  // (112 vs 145 µs, 133 vs 142 µs) and from 128 channels up.
+  auto pipe_pays = [&](double launch_flops, int Cin, bool ct) { return !no_pipe && launch_flops >= pipe_min_flops && (ct || Cin >= 128); };
   {
     int L = F;
     for (int u = 0; u < c.n_ups; u++) {
@@ -774,7 +778,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       st.tag = "conv_mfma";
       st.flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;
       st.bytes = NB * 4.0 * ((double)S.Cin * L * (cur[1] ? 3 : 1) + (double)S.Cout * Lo + (double)S.Cin * S.Cout * S.K + S.Cout);
-      const bool ct_pipe = pipe_pays(st.flops) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
+      const bool ct_pipe = pipe_pays(st.flops, S.Cin, true) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
       if (ct_pipe || (S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L))) {
         ConvWinArgs wa;
         wa.x = cur[0]; wa.x2 = cur[1]; wa.x3 = cur[2]; wa.w4 = ct_pipe ? S.up.w5 : S.up.w4; wa.bias = S.up.bias; wa.y = up;
@@ -805,7 +809,7 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       double fl = 0, by = 0;
       double launch_fl = 0;
       for (int j = 0; j < kWinMulti; j++) launch_fl += NB * conv_flops(ws[j]->Cout, ws[j]->Cin, ws[j]->K, Lo);
-      bool pipe = pipe_pays(launch_fl);
+      bool pipe = pipe_pays(launch_fl, ws[0]->Cin, false);
       for (int j = 0; j < kWinMulti; j++)
         pipe = pipe && ws[j]->w5 && conv_pipe_eligible(ws[j]->Cout, ws[j]->Cin, ws[j]->K, dil[j], (ws[j]->K * dil[j] - dil[j]) / 2, Lo, Lo);
       for (int j = 0; j < kWinMulti; j++) {
@@ -873,7 +877,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   static const bool use_win = getenv("PIPER_HIP_NO_WIN") == nullptr;  // window kernel for the generator's long rows
   static const bool no_pipe1 = getenv("PIPER_HIP_NO_PIPE") != nullptr;
   static const double pipe_min_flops1 = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
-  auto pipe_pays1 = [&](double launch_flops) { return !no_pipe1 && launch_flops >= pipe_min_flops1; };
+  auto pipe_pays1 = [&](double launch_flops, int Cin, bool ct) { return !no_pipe1 && launch_flops >= pipe_min_flops1 && (ct || Cin >= 128); };
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;
@@ -939,9 +943,25 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     s.steps.push_back(st);
   }
   const int kf = c.ffn_kernel;
+  // LayerNorms without launches of their own: the conv BEFORE a LayerNorm adds the residual and leaves per-column partial
+  // sums (stats_out), the conv AFTER it normalises its input on load (PRO_LN) and writes the normalised tensor once.
+  // PIPER_HIP_NO_LN_FUSE=1 keeps the add+LayerNorm kernels (A/B).
+  static const bool ln_fuse = getenv("PIPER_HIP_NO_LN_FUSE") == nullptr;
+  const bool ln_ok = ln_fuse && (kf == 1 || kf == 3) && v->proj.mfma;
+  float* st1 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
+  float* st2 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
+  if (ar.rc) return ar.rc;
+  auto with_ln = [&](ConvArgs a, const float* stats, const float* g, const float* be, float* normalised) {
+    a.prologue = PRO_LN;
+    a.ln_stats = stats; a.ln_gamma = g; a.ln_beta = be; a.ln_out = normalised; a.ln_eps = 1e-5f;
+    return a;
+  };
   for (int l = 0; l < c.n_layers; l++) {
     const auto& L = v->enc[l];
     const std::string p = "enc" + std::to_string(l) + ".";
+    if (ln_ok && l > 0)  // x = LN2 of the previous layer, applied to y = x1 + ffn2(…) on load; materialised into x
+      add_conv(v, s, p + "ln2_qkv", L.qkv, with_ln(plain(y, qkv, H, 3 * H, T, lensT), st2, v->enc[l - 1].g2, v->enc[l - 1].b2, x), T);
+    else
     add_conv(v, s, p + "qkv", L.qkv, plain(x, qkv, H, 3 * H, T, lensT), T);
     auto add_ln = [&](const std::string& nm, const float* a, const float* b, const float* g, const float* be, float* out) {
       Step st;
@@ -953,10 +973,11 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       };
       s.steps.push_back(st);
     };
+    bool ln1_pending = false;  // LN1 still to be applied by ffn1's prologue (y holds x + conv_o(att), st1 its statistics)
     // mm(2,T,T,96) ×2 + mm(2,T,2T−1,96) ×2
     const double att_flops = NB * 2.0 * c.n_heads * ((double)T * T * d * 2 + (double)T * (2 * T - 1) * d * 2);
     const double att_bytes = NB * 4.0 * c.n_heads * (2.0 * ((double)T * d + (double)d * T + (double)T * T) + 2.0 * ((double)T * d + (double)d * (2 * T - 1) + (double)T * (2 * T - 1)));
-    if (L.o.w16 && attention_block_eligible(c.n_heads, d, c.window, T)) {
+    if (L.o.w16 && attention_block_wanted() && attention_block_eligible(c.n_heads, d, c.window, T)) {
       // attention + conv_o + Add + LayerNorm in one launch: the block owns every channel of its 16 columns
       Step st;
       st.name = p + "attention_o_add_ln1";
@@ -986,21 +1007,33 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       st.bytes = att_bytes;
       s.steps.push_back(st);
     }
+    if (ln_ok) {  // y = x + conv_o(att) with its LayerNorm statistics; the normalisation itself happens in ffn1's prologue
+      ConvArgs a = plain(att, y, H, H, T, lensT);
+      a.res = x; a.stats_out = st1;
+      add_conv(v, s, p + "o_add_stats", L.o, a, T);
+      ln1_pending = true;
+    } else {
     add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T, lensT), T);
     add_ln(p + "add_ln1", x, y, L.g1, L.b1, x1);
     }
+    }
     {
-      ConvArgs a = plain(x1, ff, H, c.ffn, T, lensT);
+      ConvArgs a = plain(ln1_pending ? y : x1, ff, H, c.ffn, T, lensT);
       a.padL = (kf - 1) / 2;
+      if (ln1_pending) a = with_ln(a, st1, L.g1, L.b1, x1);
       a.epilogue = EPI_RELU;
-      add_conv(v, s, p + "ffn1_relu", L.f1, a, T);
+      add_conv(v, s, p + (ln1_pending ? "ln1_ffn1_relu" : "ffn1_relu"), L.f1, a, T);
       ConvArgs b = plain(ff, y, c.ffn, H, T, lensT);
       b.padL = (kf - 1) / 2;
-      add_conv(v, s, p + "ffn2", L.f2, b, T);
+      if (ln_ok) { b.res = x1; b.stats_out = st2; }
+      add_conv(v, s, p + (ln_ok ? "ffn2_add_stats" : "ffn2"), L.f2, b, T);
     }
-    add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
+    if (!ln_ok) add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
   }
   s.taps["enc_out"] = {x, H, T, 0, (size_t)H * T};
+  if (ln_ok && c.n_layers > 0)
+    add_conv(v, s, "enc.ln2_proj", v->proj, with_ln(plain(y, stats, H, 2 * I, T, lensT), st2, v->enc[c.n_layers - 1].g2, v->enc[c.n_layers - 1].b2, x), T);
+  else
   add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T, lensT), T);
   s.taps["m_p"] = {stats, I, T, 0, (size_t)2 * I * T};  // halves of the [2I, T] projection
   s.taps["logs_p"] = {stats + (size_t)I * T, I, T, 0, (size_t)2 * I * T};
@@ -1123,7 +1156,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
       st.name = p + "lrelu_convT";
       st.tag = "conv_mfma";
       const double ct_flops = NB * 2.0 * S.Cin * S.Cout * (double)S.K * L;
-      const bool ct_pipe1 = use_win && pipe_pays1(ct_flops) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
+      const bool ct_pipe1 = use_win && pipe_pays1(ct_flops, S.Cin, true) && S.up.w5 && convt_pipe_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L);
       if (ct_pipe1 || (use_win && S.up.w4 && convt_win_eligible(S.Cin, S.Cout, S.K, S.stride, S.pad, L))) {
         ConvWinArgs wa;
         wa.x = cur[0]; wa.w4 = ct_pipe1 ? S.up.w5 : S.up.w4; wa.bias = S.up.bias; wa.y = up;
@@ -1187,7 +1220,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
           Step st;
           st.name = name;
           st.flops = NB * conv_flops(w.Cout, w.Cin, w.K, Lo);
-          if (pipe_pays1(st.flops) && w.w5 && conv_pipe_eligible(w.Cout, w.Cin, w.K, a.dil, a.padL, Lo, Lo)) {
+          if (pipe_pays1(st.flops, w.Cin, false) && w.w5 && conv_pipe_eligible(w.Cout, w.Cin, w.K, a.dil, a.padL, Lo, Lo)) {
             wa.w4 = w.w5;
             st.run = [ctx, wa](hipStream_t q) { return launch_conv_pipe_multi(ctx, q, &wa, 1); };
           } else

@@ -104,6 +104,22 @@ def test_config3_batch32_mixed_lengths_vs_oracle(rt_medium, voices):
             bucketed[i] = a[k]
     for i in range(32):
         assert_close(bucketed[i], single[i], 5e-5, f"utterance {i} (factor {factors[i]}): bucketed vs one-by-one")
+    # ≤ 2 launches for the whole batch: ragged batches of the 16 longest and the 16 shortest utterances
+    order = sorted(range(32), key=lambda i: -factors[i])
+    two = [None] * 32
+    for sl, idxs in enumerate((order[:16], order[16:])):
+        rt_medium.prepare_batch(12 + sl, [utts[i] for i in idxs], 0.667)
+        rt_medium.launch(12 + sl)
+    for sl, idxs in enumerate((order[:16], order[16:])):
+        a = rt_medium.collect(12 + sl)
+        off = 0
+        for i in idxs:
+            n = 14 * factors[i] * 3 * cfg.hop
+            two[i] = a[off:off + n]
+            off += n
+        assert off == a.size
+    for i in range(32):
+        assert_close(two[i], single[i], 5e-5, f"utterance {i} (factor {factors[i]}): 2-launch ragged batch vs one-by-one")
     checked = set()
     for want in (12, 16, 1, 3, 6, 8):
         i = next(j for j, f in enumerate(factors) if f == want and j not in checked)
@@ -112,6 +128,7 @@ def test_config3_batch32_mixed_lengths_vs_oracle(rt_medium, voices):
         ref = orc.synthesize(cfg, blob, ids, dur, noise, 0.667)
         assert_close(single[i], ref, WAVE_TOL, f"utterance {i} (factor {want}) one-by-one vs oracle")
         assert_close(bucketed[i], ref, WAVE_TOL, f"utterance {i} (factor {want}) bucketed vs oracle")
+        assert_close(two[i], ref, WAVE_TOL, f"utterance {i} (factor {want}) 2-launch ragged batch vs oracle")
 
 
 def test_config4_high_bf16_factor8_vs_oracle(backend, voices):

@@ -240,9 +240,68 @@ def test_batched_utterances_share_one_schedule(rt_medium, voices):
     z = rt_medium.tap(11, "z", 4 * 192 * F).reshape(4, 192, F)
     _, taps = orc.synthesize(cfg, blob, utts[1][0], utts[1][1], utts[1][2], 0.667, taps=True)
     assert_close(z[1], taps["z"], OP_TOL, "z of batch item 1")
-    with pytest.raises(ph.ShapeMismatch):  # different Σ durations in one batch
-        rt_medium.prepare_batch(11, [utts[0], (utts[1][0], [3] * T, None)] if sum([3] * T) != F else
-                                [utts[0], (utts[1][0], [2] * T, None)], 0.667)
+
+
+def test_ragged_batch_and_bucketed_plans(rt_medium, voices):
+    """Items of DIFFERENT (T, F) in one prepare_batch: the plan is the bucket of the longest item, every length-aware kernel
+    reads the per-item true lengths from device memory (zero padding / key exclusion at each item's own end — the x_mask /
+    y_mask semantics of the reference graph). Each item must equal the oracle run alone; taps come back compacted."""
+    cfg, blob = voices["medium"]
+    rng = np.random.RandomState(21)
+    shapes = [(5, [2, 1, 3, 1, 2]), (37, None), (14, [3] * 14), (50, None), (1, [4])]
+    utts = []
+    for b, (T, dur) in enumerate(shapes):
+        ids = rng.randint(0, 130, size=T).tolist()
+        if dur is None:
+            dur = rng.randint(0, 5, size=T).tolist()
+            dur[0] = 1
+        utts.append((ids, dur, kd.sym(SD + 900 + b, (192, int(np.sum(dur))), 1.7320508)))
+    rt_medium.prepare_batch(12, utts, 0.667)
+    info = rt_medium.plan_info(12)
+    assert info["bucket_t"] == 64 and info["bucket_f"] % 16 == 0 and info["bucket_f"] >= max(int(np.sum(u[1])) for u in utts)
+    rt_medium.launch(12)
+    audio = rt_medium.collect(12)
+    z = rt_medium.tap(12, "z", sum(192 * int(np.sum(u[1])) for u in utts))
+    enc = rt_medium.tap(12, "enc_out", sum(192 * len(u[0]) for u in utts))
+    off = zoff = eoff = 0
+    for b, (ids, dur, noise) in enumerate(utts):
+        F = int(np.sum(dur))
+        ref, taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+        assert_close(enc[eoff:eoff + 192 * len(ids)], taps["enc_out"], OP_TOL, f"ragged item {b}: enc_out")
+        assert_close(z[zoff:zoff + 192 * F], taps["z"], OP_TOL, f"ragged item {b}: z")
+        assert_close(audio[off:off + F * 256], ref, WAVE_TOL, f"ragged item {b}: audio")
+        off += F * 256
+        zoff += 192 * F
+        eoff += 192 * len(ids)
+    assert off == audio.size
+    # a different utterance that fits the SAME bucket reuses the cached plan (no new graph): "warm" prepare
+    before = rt_medium.plan_info(12)["cached_plans"]
+    ids2, dur2 = rng.randint(0, 130, size=60).tolist(), [2] * 60
+    utts2 = [(ids2, dur2, None)] + utts[1:]
+    assert max(int(np.sum(u[1])) for u in utts2) <= info["bucket_f"]
+    rt_medium.prepare_batch(12, utts2, 0.667)
+    assert rt_medium.plan_info(12)["cached_plans"] == before and rt_medium.plan_info(12)["bucket_t"] == 64
+    rt_medium.launch(12)
+    a2 = rt_medium.collect(12)
+    assert_close(a2[:120 * 256], orc.synthesize(cfg, blob, ids2, dur2, None, 0.667), WAVE_TOL, "warm plan, new utterance")
+
+
+def test_plan_cache_is_bounded_and_lru(backend, voices):
+    """More distinct buckets than the cache holds: idle plans are evicted least-recently-used first, attached ones never."""
+    cfg, blob = voices["medium"]
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        rt.prepare(0, kd.FIXTURE_IDS, [3] * 14, None, 0.667)     # stays attached to slot 0 throughout
+        rt.launch(0)
+        first = rt.collect(0)
+        for T in range(16, 16 * 60, 16):                          # 59 more buckets through slot 1
+            rt.prepare(1, [1] * T, [1] * T, None, 0.667)
+        info = rt.plan_info(1)
+        assert info["cached_plans"] <= 48 and info["cached_plans"] >= 2
+        rt.launch(0)                                              # slot 0's plan survived every eviction
+        assert np.array_equal(rt.collect(0), first)
+    finally:
+        rt.close()
 
 
 def snr_db(x, ref):
