@@ -274,6 +274,15 @@ typedef struct {
   int32_t rb_n_dil; /* dilations per resblock: 2 (medium) / 3 (high) */
   int32_t rb_dilations[PIPER_HIP_MAX_RB][3];
   int32_t sample_rate; /* 22050 */
+  /* ---- ABI 2: stochastic duration predictor (VITS `dp`; the Softplus / CumSum / GatherElements / … spline arms of
+   * GraphExecutor.swift:2379-2645). dp_present = 0 ⇒ the blob carries no `dp.*` tensors and per-id durations must be
+   * supplied with every utterance. */
+  int32_t dp_present;    /* 1 */
+  int32_t dp_kernel;     /* 3: depthwise kernel of the dilated depth-separable convs; dilation kernel^i */
+  int32_t dp_dds_layers; /* 3 */
+  int32_t dp_n_flows;    /* 4 ConvFlows in the module; inference runs the last dp_n_flows − 1 of them + the ElementwiseAffine */
+  int32_t dp_bins;       /* 10 spline bins */
+  float dp_tail_bound;   /* 5.0 */
 } piper_hip_voice_config;
 
 /* Piper medium / high geometry (SURVEY.md §8a †). quality: 0 = medium, 1 = high. */

@@ -143,6 +143,44 @@ static inline size_t piper_hip_layout_walk(const piper_hip_voice_config* c, pipe
     }
   }
   piper__conv(fn, user, &off, "dec.conv_post", 1, ch, 7, 0);
+  /* stochastic duration predictor, appended (earlier offsets do not move). Module indices as in VITS: dp.flows = [ElementwiseAffine,
+   * ConvFlow, Flip, ConvFlow, Flip, …]; inference (reverse) uses flows 2·n_flows − 1, …, 3 and flow 0 — flow 1 is the one
+   * `flows[:-2] + [flows[-1]]` drops, so an export holds no initializers for it. */
+  if (c->dp_present) {
+    const long long Kd = c->dp_kernel;
+    piper__conv(fn, user, &off, "dp.pre", H, H, 1, 1);
+    piper__conv(fn, user, &off, "dp.proj", H, H, 1, 1);
+    for (int blk = 0; blk <= c->dp_n_flows - 1; blk++) { /* blk 0: the predictor's own DDSConv; blk ≥ 1: ConvFlow 2·blk + 1 */
+      char base[64];
+      if (blk == 0) snprintf(base, sizeof base, "dp");
+      else snprintf(base, sizeof base, "dp.flows.%d", 2 * blk + 1);
+      if (blk > 0) {
+        snprintf(p, sizeof p, "%s.pre", base);
+        piper__conv(fn, user, &off, p, H, 1, 1, 1);
+      }
+      for (int i = 0; i < c->dp_dds_layers; i++) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "%s.convs.convs_sep.%d.weight", base, i); /* depthwise: [H, 1, K] */
+        piper__emit(fn, user, &off, nm, PIPER_T_WEIGHT, 3, H, 1, Kd, Kd);
+        snprintf(nm, sizeof nm, "%s.convs.convs_sep.%d.bias", base, i);
+        piper__emit(fn, user, &off, nm, PIPER_T_BIAS, 1, H, 1, 1, 0);
+        snprintf(p, sizeof p, "%s.convs.convs_1x1.%d", base, i);
+        piper__conv(fn, user, &off, p, H, H, 1, 1);
+        for (int j = 1; j <= 2; j++) {
+          snprintf(nm, sizeof nm, "%s.convs.norms_%d.%d.gamma", base, j, i);
+          piper__emit(fn, user, &off, nm, PIPER_T_GAMMA, 1, H, 1, 1, 0);
+          snprintf(nm, sizeof nm, "%s.convs.norms_%d.%d.beta", base, j, i);
+          piper__emit(fn, user, &off, nm, PIPER_T_BETA, 1, H, 1, 1, 0);
+        }
+      }
+      if (blk > 0) {
+        snprintf(p, sizeof p, "%s.proj", base);
+        piper__conv(fn, user, &off, p, 3 * c->dp_bins - 1, H, 1, 1);
+      }
+    }
+    piper__emit(fn, user, &off, "dp.flows.0.m", PIPER_T_BETA, 2, 2, 1, 1, 0);
+    piper__emit(fn, user, &off, "dp.flows.0.logs", PIPER_T_BETA, 2, 2, 1, 1, 0);
+  }
   return off;
 }
 

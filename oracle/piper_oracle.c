@@ -938,3 +938,156 @@ ORC_API long orc_synthesize(const piper_hip_voice_config* cfg, const float* blob
   free(bi.descs);
   return ns_out;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Stochastic duration predictor, inference direction (VITS models.StochasticDurationPredictor.forward(reverse=True) as
+ * Piper exports it). In the reference these are ordinary graph nodes: Conv (depthwise through `group`), the LayerNorm chain
+ * (GraphExecutor.swift:2071-2125), GELU as Div / Erf / Add / Mul (Erf: elementwise.metal:292-312 is A&S 7.1.26, restated
+ * with erff — inside the stated tolerance), Softmax, Softplus (CPUBackend.swift:75-110 form), and the
+ * rational-quadratic spline spelled out with CumSum / GreaterOrEqual / ReduceSum / GatherElements / Where / Sqrt
+ * (GraphExecutor.swift:2379-2645). The reference holds no vectors for it ("parity unpinned"): pinned against
+ * tests/torch_ref.py, which is itself checked against transformers' VitsStochasticDurationPredictor (max |Δ| = 0).
+ * ---------------------------------------------------------------------------------------------- */
+static T orc_gelu(const T* x) { /* 0.5·x·(1 + erf(x / √2)): the graph's Div(√2) → Erf → Add(1) → Mul(x) → Mul(0.5) */
+  T y = *x;
+  const long n = t_count(x);
+  y.d = (float*)malloc((size_t)n * sizeof(float));
+  for (long i = 0; i < n; i++) {
+    const float v = x->d[i];
+    const float e = (float)erf((double)(v / 1.4142135381698608f));
+    y.d[i] = (v * (e + 1.0f)) * 0.5f;
+  }
+  return y;
+}
+
+static T orc_ln(const T* x, const float* gamma, const float* beta) {
+  T y = t_new(3, 1, x->s[1], x->s[2], 1);
+  orc_add_layernorm(x->d, NULL, gamma, beta, x->s[1], x->s[2], 1e-5f, y.d);
+  return y;
+}
+
+/* modules.DDSConv: x (+ g); per layer i: y = dw_conv(x, k, dilation k^i) → LN → GELU → 1×1 conv → LN → GELU; x += y */
+static T orc_dds(const blob_index* bi, const char* base, const T* x_in, const T* g) {
+  const piper_hip_voice_config* c = bi->cfg;
+  const long H = c->hidden, K = c->dp_kernel;
+  T x = g ? t_binary(0, x_in, g) : t_clone(x_in);
+  long dil = 1;
+  char f[96];
+  for (int i = 0; i < c->dp_dds_layers; i++) {
+    snprintf(f, sizeof f, "%s.convs.convs_sep.%%d", base);
+    T y = t_conv(&x, bi_get(bi, f, i, 0, ".weight"), H, K, bi_get(bi, f, i, 0, ".bias"), 1, dil, (K * dil - dil) / 2, (K * dil - dil) / 2, H);
+    snprintf(f, sizeof f, "%s.convs.norms_1.%%d", base);
+    T n1 = orc_ln(&y, bi_get(bi, f, i, 0, ".gamma"), bi_get(bi, f, i, 0, ".beta"));
+    T g1 = orc_gelu(&n1);
+    snprintf(f, sizeof f, "%s.convs.convs_1x1.%%d", base);
+    T y2 = t_conv(&g1, bi_get(bi, f, i, 0, ".weight"), H, 1, bi_get(bi, f, i, 0, ".bias"), 1, 1, 0, 0, 1);
+    snprintf(f, sizeof f, "%s.convs.norms_2.%%d", base);
+    T n2 = orc_ln(&y2, bi_get(bi, f, i, 0, ".gamma"), bi_get(bi, f, i, 0, ".beta"));
+    T g2 = orc_gelu(&n2);
+    T xn = t_binary(0, &x, &g2);
+    t_free(&y); t_free(&n1); t_free(&g1); t_free(&y2); t_free(&n2); t_free(&g2); t_free(&x);
+    x = xn;
+    dil *= K;
+  }
+  return x;
+}
+
+static float orc_softplus(float v) { return v > 0 ? v + (float)log(1.0 + exp((double)-v)) : (float)log(1.0 + exp((double)v)); }
+
+/* transforms.unconstrained_rational_quadratic_spline(inverse=True, tails='linear'), one element: x = z1[t], h = the 3·bins − 1
+ * channels of ConvFlow.proj at t. float arithmetic in the graph's order. */
+static float orc_spline_inverse(float x, const float* h, long stride, int nb, float B, float filter_channels) {
+  if (!(x >= -B && x <= B)) return x; /* outside the interval: identity */
+  const float mbw = 1e-3f, mbh = 1e-3f, md = 1e-3f;
+  const float inv = sqrtf(filter_channels);
+  float w[32], hh[32], cw[33], ch[33], d[33];
+  float mw = -INFINITY, mh = -INFINITY;
+  for (int i = 0; i < nb; i++) {
+    w[i] = h[i * stride] / inv;
+    hh[i] = h[(nb + i) * stride] / inv;
+    if (w[i] > mw) mw = w[i];
+    if (hh[i] > mh) mh = hh[i];
+  }
+  float sw = 0, sh = 0;
+  for (int i = 0; i < nb; i++) { w[i] = expf(w[i] - mw); sw += w[i]; hh[i] = expf(hh[i] - mh); sh += hh[i]; }
+  cw[0] = 0; ch[0] = 0;
+  for (int i = 0; i < nb; i++) {
+    const float wi = mbw + (1 - mbw * nb) * (w[i] * (1.0f / sw));
+    const float hi = mbh + (1 - mbh * nb) * (hh[i] * (1.0f / sh));
+    cw[i + 1] = cw[i] + wi;
+    ch[i + 1] = ch[i] + hi;
+  }
+  for (int i = 0; i <= nb; i++) { cw[i] = (2 * B) * cw[i] + -B; ch[i] = (2 * B) * ch[i] + -B; }
+  cw[0] = -B; cw[nb] = B; ch[0] = -B; ch[nb] = B;
+  const float constant = (float)log(exp(1.0 - (double)md) - 1.0);
+  d[0] = md + orc_softplus(constant);
+  d[nb] = d[0];
+  for (int i = 1; i < nb; i++) d[i] = md + orc_softplus(h[(2 * nb + i - 1) * stride]);
+  int idx = -1; /* Σ (x ≥ location) − 1, the last location nudged by 1e-6 */
+  for (int i = 0; i <= nb; i++) idx += x >= (i == nb ? ch[i] + 1e-6f : ch[i]);
+  if (idx < 0) idx = 0;
+  if (idx > nb - 1) idx = nb - 1;
+  const float ibw = cw[idx + 1] - cw[idx], ih = ch[idx + 1] - ch[idx];
+  const float idl = ih / ibw;
+  const float i1 = d[idx] + d[idx + 1] - 2 * idl;
+  const float i2 = x - ch[idx];
+  const float i3 = i2 * i1;
+  const float a = ih * (idl - d[idx]) + i3;
+  const float b = ih * d[idx] - i3;
+  const float cc = -idl * i2;
+  const float disc = b * b - 4 * a * cc;
+  const float root = (2 * cc) / (-b - sqrtf(disc));
+  return root * ibw + cw[idx];
+}
+
+/* enc_out [H,T] (text-encoder output, the predictor's `x`), dp_noise [2,T] (the `dp` RandomNormalLike tensor; NULL = zeros),
+ * noise_w (scales[2]) → logw [T]. */
+ORC_API int orc_duration_logw(const piper_hip_voice_config* cfg, const float* blob, const float* enc_out, long T_, const float* dp_noise,
+                              float noise_w, float* logw) {
+  if (!cfg->dp_present) return -1;
+  blob_index bi = {cfg, blob, NULL, 0, 0};
+  piper_hip_layout_walk(cfg, bi_visit, &bi);
+  const long H = cfg->hidden;
+  const int nb = cfg->dp_bins;
+  T x0 = t_new(3, 1, H, T_, 1);
+  memcpy(x0.d, enc_out, (size_t)(H * T_) * sizeof(float));
+  T x1 = t_conv(&x0, bi_get(&bi, "dp.pre", 0, 0, ".weight"), H, 1, bi_get(&bi, "dp.pre", 0, 0, ".bias"), 1, 1, 0, 0, 1);
+  T x2 = orc_dds(&bi, "dp", &x1, NULL);
+  T x = t_conv(&x2, bi_get(&bi, "dp.proj", 0, 0, ".weight"), H, 1, bi_get(&bi, "dp.proj", 0, 0, ".bias"), 1, 1, 0, 0, 1);
+  t_free(&x0); t_free(&x1); t_free(&x2);
+  float* z = (float*)calloc((size_t)(2 * T_), sizeof(float)); /* [2][T] */
+  if (dp_noise)
+    for (long i = 0; i < 2 * T_; i++) z[i] = dp_noise[i] * noise_w;
+  for (int f = 2 * cfg->dp_n_flows - 1; f > 1; f -= 2) { /* Flip, ConvFlow f (reverse) */
+    for (long t = 0; t < T_; t++) { const float a = z[t]; z[t] = z[T_ + t]; z[T_ + t] = a; }
+    char base[64];
+    snprintf(base, sizeof base, "dp.flows.%d", f);
+    T z0 = t_new(3, 1, 1, T_, 1);
+    memcpy(z0.d, z, (size_t)T_ * sizeof(float));
+    char nm[96];
+    snprintf(nm, sizeof nm, "%s.pre", base);
+    T h0 = t_conv(&z0, bi_get(&bi, nm, 0, 0, ".weight"), H, 1, bi_get(&bi, nm, 0, 0, ".bias"), 1, 1, 0, 0, 1);
+    T h1 = orc_dds(&bi, base, &h0, &x);
+    snprintf(nm, sizeof nm, "%s.proj", base);
+    T h2 = t_conv(&h1, bi_get(&bi, nm, 0, 0, ".weight"), 3 * nb - 1, 1, bi_get(&bi, nm, 0, 0, ".bias"), 1, 1, 0, 0, 1);
+    for (long t = 0; t < T_; t++) z[T_ + t] = orc_spline_inverse(z[T_ + t], h2.d + t, T_, nb, cfg->dp_tail_bound, (float)H);
+    t_free(&z0); t_free(&h0); t_free(&h1); t_free(&h2);
+  }
+  for (long t = 0; t < T_; t++) { const float a = z[t]; z[t] = z[T_ + t]; z[T_ + t] = a; } /* Flip before the ElementwiseAffine */
+  const float* m = bi_get(&bi, "dp.flows.0.m", 0, 0, "");
+  const float* lg = bi_get(&bi, "dp.flows.0.logs", 0, 0, "");
+  for (long t = 0; t < T_; t++) logw[t] = (z[t] - m[0]) * (float)exp((double)-lg[0]);
+  t_free(&x);
+  free(z);
+  free(bi.descs);
+  return 0;
+}
+
+/* w = exp(logw)·length_scale; durations = ceil(w) (Piper infer; Exp / Mul / Ceil arms), as int32 frames per id (≥ 0). */
+ORC_API void orc_durations_from_logw(const float* logw, long T_, float length_scale, int32_t* dur) {
+  for (long t = 0; t < T_; t++) {
+    const float w = (float)exp((double)logw[t]) * length_scale;
+    const float cw = (float)ceil((double)w);
+    dur[t] = cw > 0 ? (cw < 1e6f ? (int32_t)cw : 1000000) : 0;
+  }
+}

@@ -947,7 +947,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   // sums (stats_out), the conv AFTER it normalises its input on load (PRO_LN) and writes the normalised tensor once.
   // PIPER_HIP_NO_LN_FUSE=1 keeps the add+LayerNorm kernels (A/B).
   static const bool ln_fuse = getenv("PIPER_HIP_NO_LN_FUSE") == nullptr;
-  const bool ln_ok = ln_fuse && (kf == 1 || kf == 3) && v->proj.mfma;
+  const bool ln_ok = ln_fuse && (kf == 1 || kf == 3) && v->proj.mfma && H <= 256;
   float* st1 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   float* st2 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   if (ar.rc) return ar.rc;

@@ -21,6 +21,7 @@ PH_EXPORT int piper_hip_voice_config_preset(int quality, piper_hip_voice_config*
   c->wn_kernel = 5;
   c->n_rb = 3;
   c->sample_rate = 22050;
+  c->dp_present = 1; c->dp_kernel = 3; c->dp_dds_layers = 3; c->dp_n_flows = 4; c->dp_bins = 10; c->dp_tail_bound = 5.0f;
   if (quality == 0) {  // medium: ResBlock2, 256 ch, rates 8,8,4
     c->up_initial = 256;
     c->n_ups = 3;
@@ -83,6 +84,11 @@ int validate_config(const piper_hip_voice_config* c) {
       if (c->rb_dilations[j][d] < 1 || c->rb_dilations[j][d] > 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "resblock %d: dilation %d out of [1,64]", j, c->rb_dilations[j][d]);
   }
   if (c->sample_rate < 0 || c->sample_rate > 384000) PH_FAIL(PIPER_HIP_ERR_SHAPE, "sample_rate out of range");
+  if (c->dp_present) {
+    if (c->dp_present != 1 || c->dp_kernel < 1 || c->dp_kernel > 7 || !(c->dp_kernel & 1) || c->dp_dds_layers < 1 || c->dp_dds_layers > 4 ||
+        c->dp_n_flows < 2 || c->dp_n_flows > 8 || c->dp_bins < 2 || c->dp_bins > 32 || !(c->dp_tail_bound > 0.0f) || c->dp_tail_bound > 100.0f)
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "duration predictor geometry unsupported");
+  }
   return PIPER_HIP_OK;
 }
 }  // namespace ph

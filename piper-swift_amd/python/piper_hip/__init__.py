@@ -77,7 +77,8 @@ class VoiceConfig(C.Structure):
                                          "inter", "n_flows", "wn_layers", "wn_kernel", "up_initial", "n_ups")] + [
         ("up_rates", C.c_int32 * 4), ("up_kernels", C.c_int32 * 4), ("resblock_type", C.c_int32), ("n_rb", C.c_int32),
         ("rb_kernels", C.c_int32 * 3), ("rb_n_dil", C.c_int32), ("rb_dilations", (C.c_int32 * 3) * 3),
-        ("sample_rate", C.c_int32)]
+        ("sample_rate", C.c_int32), ("dp_present", C.c_int32), ("dp_kernel", C.c_int32), ("dp_dds_layers", C.c_int32),
+        ("dp_n_flows", C.c_int32), ("dp_bins", C.c_int32), ("dp_tail_bound", C.c_float)]
 
     @property
     def hop(self):

@@ -261,3 +261,19 @@ def synthesize(cfg, blob, ids, durations, noise, noise_scale, taps=False):
                              _f(t["enc_out"]), _f(t["m_p"]), _f(t["logs_p"]), _f(t["z_p"]), _f(t["z"]))
     assert n == audio.size, (n, audio.size)
     return (audio, t) if taps else audio
+
+
+def duration_logw(cfg, blob, enc_out, dp_noise, noise_w):
+    enc = _c(enc_out)
+    T = enc.shape[-1]
+    nz = None if dp_noise is None else _c(dp_noise)
+    out = np.zeros(T, np.float32)
+    assert lib().orc_duration_logw(C.byref(cfg), _f(blob), _f(enc), C.c_long(T), _f(nz), C.c_float(noise_w), _f(out)) == 0
+    return out
+
+
+def durations_from_logw(logw, length_scale=1.0):
+    lw = _c(logw)
+    d = np.zeros(lw.size, np.int32)
+    lib().orc_durations_from_logw(_f(lw), C.c_long(lw.size), C.c_float(length_scale), d.ctypes.data_as(C.POINTER(C.c_int32)))
+    return d

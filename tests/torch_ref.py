@@ -164,6 +164,84 @@ class Ref:
         x = Fn.conv1d(x, self.w["dec.conv_post.weight"], None, padding=3)
         return torch.tanh(x)
 
+    # ---- stochastic duration predictor, reverse (VITS models.StochasticDurationPredictor / modules.DDSConv / ConvFlow /
+    # ElementwiseAffine / transforms.piecewise_rational_quadratic_transform; Piper infer: w = exp(logw)·mask·length_scale)
+    def dds(self, base, x, g=None):
+        c = self.cfg
+        if g is not None:
+            x = x + g
+        K = c.dp_kernel
+        for i in range(c.dp_dds_layers):
+            dil = K ** i
+            y = Fn.conv1d(x, self.w[f"{base}.convs.convs_sep.{i}.weight"], self.w[f"{base}.convs.convs_sep.{i}.bias"], dilation=dil,
+                          padding=(K * dil - dil) // 2, groups=x.shape[1])
+            y = Fn.gelu(self.layernorm(y, self.w[f"{base}.convs.norms_1.{i}.gamma"], self.w[f"{base}.convs.norms_1.{i}.beta"]))
+            y = self.conv(f"{base}.convs.convs_1x1.{i}", y)
+            y = Fn.gelu(self.layernorm(y, self.w[f"{base}.convs.norms_2.{i}.gamma"], self.w[f"{base}.convs.norms_2.{i}.beta"]))
+            x = x + y
+        return x
+
+    def spline_inverse(self, x1, h):
+        """x1 [1,1,T]; h [1, 3·bins − 1, T] (ConvFlow.proj output) → inverse rational-quadratic spline with linear tails."""
+        c = self.cfg
+        nb, B, fc = c.dp_bins, float(c.dp_tail_bound), float(c.hidden)
+        h = h[0].transpose(0, 1)  # [T, 29]
+        uw, uh, ud = h[:, :nb] / (fc ** 0.5), h[:, nb:2 * nb] / (fc ** 0.5), h[:, 2 * nb:]
+        mbw = mbh = md = 1e-3
+        const = float(np.log(np.exp(1 - md) - 1))
+        ud = Fn.pad(ud, (1, 1), value=const)
+        x = x1[0, 0]
+        inside = (x >= -B) & (x <= B)
+        widths = mbw + (1 - mbw * nb) * Fn.softmax(uw, -1)
+        cw = Fn.pad(torch.cumsum(widths, -1), (1, 0)) * (2 * B) - B
+        cw[:, 0], cw[:, -1] = -B, B
+        widths = cw[:, 1:] - cw[:, :-1]
+        derivs = md + Fn.softplus(ud)
+        heights = mbh + (1 - mbh * nb) * Fn.softmax(uh, -1)
+        chh = Fn.pad(torch.cumsum(heights, -1), (1, 0)) * (2 * B) - B
+        chh[:, 0], chh[:, -1] = -B, B
+        heights = chh[:, 1:] - chh[:, :-1]
+        loc = chh.clone()
+        loc[:, -1] += 1e-6
+        idx = (torch.sum(x[:, None] >= loc, -1) - 1).clamp(0, nb - 1)[:, None]
+        g = lambda tns: tns.gather(-1, idx)[:, 0]
+        icw, ibw, ich, ih = g(cw), g(widths), g(chh), g(heights)
+        idl = g(heights / widths)
+        d0, d1 = g(derivs), g(derivs[:, 1:])
+        i1 = d0 + d1 - 2 * idl
+        i2 = x - ich
+        i3 = i2 * i1
+        a = ih * (idl - d0) + i3
+        b = ih * d0 - i3
+        cc = -idl * i2
+        root = (2 * cc) / (-b - torch.sqrt(b * b - 4 * a * cc))
+        out = torch.where(inside, root * ibw + icw, x)
+        return out.reshape(1, 1, -1)
+
+    def duration_logw(self, enc_out, dp_noise, noise_w):
+        """enc_out [1,H,T] (text-encoder output), dp_noise [2,T] (the `dp` RandomNormalLike tensor) → logw [T]."""
+        c = self.cfg
+        x = self.conv("dp.pre", enc_out)
+        x = self.dds("dp", x)
+        x = self.conv("dp.proj", x)
+        z = t(np.ascontiguousarray(dp_noise, np.float32)).reshape(1, 2, -1) * noise_w
+        for f in range(2 * c.dp_n_flows - 1, 1, -2):  # ConvFlows 7, 5, 3 — each preceded by a Flip
+            z = torch.flip(z, [1])
+            z0, z1 = z[:, :1], z[:, 1:]
+            h = self.conv(f"dp.flows.{f}.pre", z0)
+            h = self.dds(f"dp.flows.{f}", h, g=x)
+            h = self.conv(f"dp.flows.{f}.proj", h)
+            z = torch.cat([z0, self.spline_inverse(z1, h)], 1)
+        z = torch.flip(z, [1])
+        z = (z - self.w["dp.flows.0.m"].reshape(1, 2, 1)) * torch.exp(-self.w["dp.flows.0.logs"].reshape(1, 2, 1))
+        return z[0, 0]
+
+    def durations(self, ids, dp_noise, noise_w, length_scale):
+        enc, _ = self.text_encoder(ids)
+        logw = self.duration_logw(enc, dp_noise, noise_w)
+        w = torch.exp(logw) * length_scale
+        return torch.ceil(w).to(torch.int64).numpy(), logw.numpy()
+
     def synthesize(self, ids, durations, noise, noise_scale):
         c = self.cfg
         enc, stats = self.text_encoder(ids)
@@ -247,6 +325,33 @@ def hf_crosscheck(cfg_m, blob_m, cfg_h, blob_h):
         gen.conv_post.weight.copy_(ref_h.w["dec.conv_post.weight"])
         z = t(kd.sym(55, (1, 192, 4)))
         rep["hifigan_high"] = float((ref_h.generator(z) - gen(z)).abs().max())
+        # stochastic duration predictor, reverse mode (noise injected by patching torch.randn for the call)
+        if getattr(cfg_m, "dp_present", 0):
+            sdp = mv.VitsStochasticDurationPredictor(hc).eval()
+            def cp(dst, name):
+                dst.weight.copy_(ref_m.w[name + ".weight"]); dst.bias.copy_(ref_m.w[name + ".bias"])
+            def cp_dds(dds, base):
+                for i in range(cfg_m.dp_dds_layers):
+                    cp(dds.convs_dilated[i], f"{base}.convs.convs_sep.{i}")
+                    cp(dds.convs_pointwise[i], f"{base}.convs.convs_1x1.{i}")
+                    for j, lst in ((1, dds.norms_1), (2, dds.norms_2)):
+                        lst[i].weight.copy_(ref_m.w[f"{base}.convs.norms_{j}.{i}.gamma"]); lst[i].bias.copy_(ref_m.w[f"{base}.convs.norms_{j}.{i}.beta"])
+            cp(sdp.conv_pre, "dp.pre"); cp(sdp.conv_proj, "dp.proj"); cp_dds(sdp.conv_dds, "dp")
+            sdp.flows[0].translate.copy_(ref_m.w["dp.flows.0.m"]); sdp.flows[0].log_scale.copy_(ref_m.w["dp.flows.0.logs"])
+            for j in range(2, cfg_m.dp_n_flows + 1):  # HF flows[j] = VITS dp.flows[2j − 1]
+                fl = sdp.flows[j]
+                cp(fl.conv_pre, f"dp.flows.{2 * j - 1}.pre"); cp(fl.conv_proj, f"dp.flows.{2 * j - 1}.proj"); cp_dds(fl.conv_dds, f"dp.flows.{2 * j - 1}")
+            for T in (5, 14, 50):
+                enc = t(kd.sym(300 + T, (1, 192, T)))
+                nz = kd.sym(310 + T, (2, T), 1.7320508)
+                mine = ref_m.duration_logw(enc, nz, 0.8)
+                orig = torch.randn
+                torch.randn = lambda *a, **k: t(nz).reshape(1, 2, T)
+                try:
+                    theirs = sdp(enc, torch.ones(1, 1, T), reverse=True, noise_scale=0.8)[0, 0]
+                finally:
+                    torch.randn = orig
+                rep[f"duration_predictor_T{T}"] = float((mine - theirs).abs().max())
     for k, v in rep.items():
         print(f"  HF cross-check {k}: max|Δ| = {v:.3e}")
         assert v < 2e-4, (k, v)
