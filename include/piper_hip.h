@@ -376,16 +376,26 @@ int piper_hip_wav_write(const char* path, const float* samples, size_t n, int32_
 typedef struct {
   const int64_t* phoneme_ids; /* [T] host */
   int32_t t;
-  const int32_t* durations; /* [T] host, frames per id (≥0); F = Σ durations */
+  const int32_t* durations; /* [T] host, frames per id (≥0), F = Σ durations — the `overrides` route; NULL: predicted on the device
+                               by the voice's stochastic duration predictor from length_scale / noise_w / dp_noise (ABI 2) */
   const float* noise;       /* `main` RandomNormalLike [inter, F] host, may be NULL (see noise_mode) */
   float noise_scale;        /* scales[0] */
   /* ---- ABI 2 ---- */
   int32_t noise_mode;       /* PIPER_HIP_NOISE_INJECTED / PIPER_HIP_NOISE_DEVICE */
   uint32_t seed;            /* PIPER_HIP_NOISE_DEVICE: RandomNormalLike seed; the reference hard-codes 1234 (GraphExecutor.swift:2658) */
+  float length_scale;       /* scales[1]: w = exp(logw)·length_scale (only read when durations == NULL; 0 is taken as 1.0) */
+  float noise_w;            /* scales[2]: scale of the predictor's latent noise (only read when durations == NULL) */
+  const float* dp_noise;    /* `dp` RandomNormalLike [2, T] host, may be NULL (see noise_mode; both RandomNormalLike nodes of the
+                               reference draw from the SAME seed, so device mode reproduces that) */
 } piper_hip_utterance;
 
-/* Samples `synthesize` will produce for this utterance (F · Π up_rates). */
+/* Samples `synthesize` will produce for this utterance (F · Π up_rates); −1 on a bad utterance, −2 when the durations are to
+ * be predicted (unknown before `prepare`: ask piper_hip_voice_prepared_samples afterwards). */
 int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_utterance* u);
+/* After prepare: samples of each batch item of the slot (n_items entries) and/or their sum. */
+int piper_hip_voice_prepared_samples(const piper_hip_voice* v, int slot, int64_t* per_item, int max_items, int64_t* total);
+/* After prepare: the frames-per-id actually used (supplied or predicted), items back to back (Σ T_b entries). */
+int piper_hip_voice_durations(const piper_hip_voice* v, int slot, int32_t* out, int max_entries, int* n_entries);
 /* Attach a plan for this utterance's bucket to `slot` (building and caching it if the voice has none idle) and upload the
  * utterance's inputs; returns the slot id ≥ 0. Plans own a stream and an arena, so several prepared slots can be launched
  * back-to-back and overlap on the GPU. */
@@ -409,6 +419,11 @@ int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot);
 int piper_hip_voice_launch(piper_hip_voice* v, int slot);
 /* Wait for the slot and copy the waveform(s) [batch · num_samples] to host (NULL = just wait). */
 int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_audio, int64_t max_samples);
+/* The duration predictor alone (text encoder + `dp` of the graph): frames per id for `n` utterances (their `durations` fields are
+ * ignored), items back to back in `durations_out` (Σ T_b entries); `logw_out` (optional, same length) receives the predictor's
+ * log-durations before exp / length_scale / ceil. This is what `prepare` runs first when an utterance has durations == NULL. */
+int piper_hip_voice_predict_durations(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out,
+                                      int max_entries);
 /* Streaming ⇔ PiperMetalRuntime.synthesizeStream (PiperMetalRuntime.swift:82-115) — which "today chunks the final
  * waveform". Here the text encoder and the flow run once (stream_begin) and the HiFi-GAN generator decodes the latent
  * window by window: each stream_next decodes `chunk_frames` frames plus the generator's receptive field on both sides
@@ -425,7 +440,8 @@ int piper_hip_voice_synthesize(piper_hip_voice* v, const piper_hip_utterance* u,
 /* Debug taps ⇔ GraphExecutor.execute(maxNodeIndex:) returning intermediates (GraphExecutor.swift:75-152):
  * copy a named intermediate of the slot's last run to host. Names: "enc_out" [H,T], "m_p" [inter,T],
  * "logs_p" [inter,T], "z_p" [inter,F], "z" [inter,F], "dec_pre" [up_initial,F] — per batch item, compacted to the item's
- * true T / F (the bucket's padding is not copied), items back to back. */
+ * true T / F (the bucket's padding is not copied), items back to back. With predicted durations, "logw" [1,T] of the
+ * predictor is available through piper_hip_voice_predict_durations. */
 int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name, float* host, size_t max_floats,
                         size_t* n_floats);
 /* GPU milliseconds of the slot's last completed launch (hipEvent pair on the slot's stream) ⇔

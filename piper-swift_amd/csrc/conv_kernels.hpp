@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       // ~1–2 waves per SIMD (all a short utterance offers) this is what covers the 0.3–2 µs load latency.
       // PRO_LN: statistics of this lane's columns (one per tap and time tile), from the producer's per-slot partial sums
       float lnm[PRO == PRO_LN ? K : 1][NT], lns[PRO == PRO_LN ? K : 1][NT];
-      if constexpr (PRO == PRO_LN) {
+      auto load_ln_stats = [&]() {
         // The lanes that share a column (64 / TM of them: lane groups kk) split the producer's slots among themselves, every
         // load is independent (ONE memory round trip; a serial loop over the 12 slots cost 12 of them: r2g, +7 µs per conv),
         // then the group sums are exchanged by lane shuffles. Fixed association ⇒ deterministic.
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
             lnm[k][nt] = mean;
             lns[k][nt] = sqrtf(var + p.ln_eps);
           }
-      }
+      };
       constexpr int regs_per_group = S * (NA + NX * NT) + (PRO == PRO_LN ? 2 * G : 0);
       constexpr int D = BT > 256 ? 2 : (regs_per_group * 4 <= 112 ? 4 : (regs_per_group * 3 <= 132 ? 3 : 2));
       float av[D][NA][S], bv[D][NX][S][NT];
@@ -388,6 +388,8 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       if (g_begin < g_end) {
         const int g_last = g_end - 1;
         static_for<D - 1>([&](auto d) { fetch(d, min(g_begin + d.value, g_last)); });
+        // the statistics are requested BEHIND the first operand groups: one memory round trip covers both
+        if constexpr (PRO == PRO_LN) load_ln_stats();
         for (int g = g_begin; g < g_end; g += D) {
           static_for<D>([&](auto d) {
             const int gg = g + d.value;

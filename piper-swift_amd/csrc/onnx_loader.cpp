@@ -503,6 +503,19 @@ PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voi
       cfg->rb_dilations[j][d] = (int32_t)dl;
     }
   }
+  // stochastic duration predictor (absent ⇒ dp_present = 0: durations must then be supplied per utterance)
+  if (has("dp.pre.weight") && has("dp.flows.0.m")) {
+    cfg->dp_present = 1;
+    if (!(t = need("dp.convs.convs_sep.0.weight", 3))) return PIPER_HIP_ERR_ARG;
+    cfg->dp_kernel = (int32_t)t->dims[2];
+    while (cfg->dp_dds_layers < 8 && has(fmt("dp.convs.convs_sep.%d.weight", cfg->dp_dds_layers))) cfg->dp_dds_layers++;
+    int used = 0;  // ConvFlows present: module indices 3, 5, … (flow 1 is dropped by the reverse pass, so not exported)
+    while (used < 16 && has(fmt("dp.flows.%d.pre.weight", 2 * used + 3))) used++;
+    cfg->dp_n_flows = used + 1;
+    if (!(t = need("dp.flows.3.proj.weight", 3))) return PIPER_HIP_ERR_ARG;
+    cfg->dp_bins = (int32_t)((t->dims[0] + 1) / 3);
+    cfg->dp_tail_bound = 5.0f;  // a constant folded into the graph, not an initializer: VITS' fixed value
+  }
   cfg->sample_rate = 22050;  // lives in the voice's .onnx.json (piper_hip_piper_json), not in the graph
   size_t n = 0;
   return piper_hip_voice_blob_floats(cfg, &n);  // validates the geometry

@@ -29,6 +29,16 @@ int validate_config(const piper_hip_voice_config* c);
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
                          int64_t out_batch_stride, const int* len_ptr);
+size_t dp_scalars_bytes(int n);
+void dp_scalars_fill(void* host, int i, float noise_w, float length_scale, unsigned gen, unsigned seed);
+bool dds_layer_eligible(int H, int K);
+int launch_dds_layer(piper_hip_ctx* ctx, hipStream_t s, const float* x, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
+                     const float* pw16, const float* pw_b, const float* g2, const float* b2, float* out, int N, int H, int T, int K, int dil,
+                     int pw_steps, const int* len_ptr, float eps);
+int launch_dp_init(hipStream_t s, const float* noise, const void* scalars, float* z, int N, int T, const int* len_ptr);
+int launch_dp_spline(hipStream_t s, const float* h, float* z, int N, int T, int bins, float tail_bound, float filter_channels, const int* len_ptr);
+int launch_dp_final(hipStream_t s, const float* z, const float* m, const float* logs, const void* scalars, float* logw, int32_t* dur, int N, int T,
+                    const int* len_ptr);
 bool attention_block_eligible(int H, int d, int w, int T);
 bool attention_block_wanted();
 int launch_attention_block(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev,
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const int64_t* __restrict
 __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __restrict__ stats, const int32_t* __restrict__ frame2id,
                                                               const float* __restrict__ noise, float* __restrict__ zp, float* __restrict__ zp_tap,
                                                               int I, int T, int F, const float* __restrict__ noise_scale_dev,
-                                                              const unsigned* __restrict__ rng_dev) {
+                                                              const unsigned* __restrict__ rng_dev, const int* __restrict__ lensF) {
   const int nb = blockIdx.y;  // batch item
   stats += (int64_t)nb * 2 * I * T;
   frame2id += (int64_t)nb * F;
@@ -76,13 +86,14 @@ __global__ __launch_bounds__(kBlock) void expand_noise_kernel(const float* __res
   // item's [1, I, F] tensor; rng_dev[2nb] = generate?, rng_dev[2nb+1] = seed. Otherwise the injected tensor is read.
   const bool gen = rng_dev[2 * nb] != 0u;
   const unsigned seed = rng_dev[2 * nb + 1];
+  const int Fv = lensF ? min(lensF[nb], F) : F;  // RandomNormalLike mirrors the item's TRUE [1, I, Fv] shape, not the bucket
   const int64_t total = (int64_t)I * F;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
     const int c = (int)(i / F), f = (int)(i - (int64_t)c * F);
     const int t = frame2id[f];
     const float m = stats[(int64_t)c * T + t];
     const float lg = stats[(int64_t)(I + c) * T + t];
-    const float nz = gen ? rnl_normal(seed, (unsigned)i) : noise[i];
+    const float nz = gen ? (f < Fv ? rnl_normal(seed, (unsigned)(c * Fv + f)) : 0.0f) : noise[i];
     const float r = m + (nz * expf(lg)) * noise_scale;
     zp[i] = r;      // updated in place by the flow couplings
     zp_tap[i] = r;  // pristine copy for the "z_p" debug tap
@@ -170,6 +181,11 @@ struct Slot {
   int* lensT = nullptr;    // [NB] device: true phoneme count per item
   int* lensF = nullptr;    // [NB] device: true frame count per item
   std::vector<int> h_T, h_F;   // the same on the host (collect / tap / streaming)
+  // duration-predictor plan (kind 2): encoder + predictor → frames per id
+  float* dp_noise = nullptr;   // [NB][2][T] injected `dp` RandomNormalLike tensor
+  void* dp_scalars = nullptr;  // [NB] DpScalars (device)
+  int32_t* dp_dur = nullptr;   // [NB][T] predicted frames per id
+  std::vector<int32_t> h_dur;  // predicted durations of the attached request, per item back to back (host)
   int* h_lens = nullptr;       // pinned staging [2·NB]
   size_t h_cap_lens = 0;
   // device buffers
@@ -230,6 +246,17 @@ struct piper_hip_voice {
   };
   std::vector<Coupling> flows;
   ConvW conv_pre, conv_post;
+  struct DdsLayer {
+    const float *dw_w, *dw_b, *g1, *b1, *g2, *b2;
+    ConvW pw;  // 1×1 conv: the 16-wide fragment image (w16) is what dds_layer_kernel reads
+  };
+  struct DpBlock {  // the predictor's own stack (flow = 0) or one ConvFlow
+    int flow = 0;
+    ConvW pre, proj;
+    std::vector<DdsLayer> dds;
+  };
+  std::vector<DpBlock> dp;  // [0] main, then the ConvFlows in EXECUTION order (module indices 7, 5, 3)
+  const float *dp_m = nullptr, *dp_logs = nullptr;
   struct Stage {
     ConvW up;  // packed ConvTranspose (rows = Cout·stride)
     int Cin, Cout, K, stride, pad;
@@ -410,6 +437,41 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
     v->stages.push_back(S);
   }
   v->conv_post = make_conv(pk, dry, "dec.conv_post", 1, ch, 7, false);
+  v->dp.clear();
+  if (c.dp_present) {
+    auto dds_of = [&](const std::string& base) {
+      std::vector<piper_hip_voice::DdsLayer> out;
+      for (int i = 0; i < c.dp_dds_layers; i++) {
+        piper_hip_voice::DdsLayer d{};
+        const std::string sep = base + ".convs.convs_sep." + std::to_string(i), n1 = base + ".convs.norms_1." + std::to_string(i),
+                          n2 = base + ".convs.norms_2." + std::to_string(i);
+        d.pw = make_conv(pk, dry, base + ".convs.convs_1x1." + std::to_string(i), H, H, 1);
+        if (!dry) {
+          d.dw_w = tensor(v, sep + ".weight"); d.dw_b = tensor(v, sep + ".bias");
+          d.g1 = tensor(v, n1 + ".gamma"); d.b1 = tensor(v, n1 + ".beta");
+          d.g2 = tensor(v, n2 + ".gamma"); d.b2 = tensor(v, n2 + ".beta");
+        }
+        out.push_back(d);
+      }
+      return out;
+    };
+    piper_hip_voice::DpBlock m;
+    m.flow = 0;
+    m.pre = make_conv(pk, dry, "dp.pre", H, H, 1);
+    m.proj = make_conv(pk, dry, "dp.proj", H, H, 1);
+    m.dds = dds_of("dp");
+    v->dp.push_back(m);
+    for (int f = 2 * c.dp_n_flows - 1; f > 1; f -= 2) {
+      piper_hip_voice::DpBlock b;
+      const std::string base = "dp.flows." + std::to_string(f);
+      b.flow = f;
+      b.pre = make_conv(pk, dry, base + ".pre", H, 1, 1);             // 1 → H: direct kernel
+      b.proj = make_conv(pk, dry, base + ".proj", 3 * c.dp_bins - 1, H, 1);
+      b.dds = dds_of(base);
+      v->dp.push_back(b);
+    }
+    if (!dry) { v->dp_m = tensor(v, "dp.flows.0.m"); v->dp_logs = tensor(v, "dp.flows.0.logs"); }
+  }
   return PIPER_HIP_OK;
 }
 
@@ -419,6 +481,7 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
   if (s.front_exec) { (void)hipGraphExecDestroy(s.front_exec); s.front_exec = nullptr; }
   if (s.front_graph) { (void)hipGraphDestroy(s.front_graph); s.front_graph = nullptr; }
   s.st_next = -1; s.zin = nullptr; s.z_out = nullptr;
+  s.dp_noise = nullptr; s.dp_scalars = nullptr; s.dp_dur = nullptr;
   for (void* p : s.owned) (void)v->ctx->pool.release(p);
   s.owned.clear();
   s.steps.clear();
@@ -868,7 +931,12 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   return PIPER_HIP_OK;
 }
 
-int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_only = false) {
+// the duration predictor on the encoder output x [NB][H][T]: → s.dp_dur / "logw" tap
+int build_duration_predictor(piper_hip_voice* v, Slot& s, Arena& ar, const float* x, int T, int NB);
+
+// mode 0: whole utterance; 1: generator only (streaming window); 2: text encoder + duration predictor
+int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode = 0) {
+  const bool gen_only = mode == 1;
   const piper_hip_voice_config& c = v->cfg;
   piper_hip_ctx* ctx = v->ctx;
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
@@ -881,7 +949,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;
-  s.kind = gen_only ? 1 : 0;
+  s.kind = mode;
   s.prec = v->precision;
   s.arena_bytes = 0;
   s.parallel = parallel_rb;
@@ -1031,6 +1099,20 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     if (!ln_ok) add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
   }
   s.taps["enc_out"] = {x, H, T, 0, (size_t)H * T};
+  if (mode == 2) {  // x must exist in memory for the predictor: with the LayerNorm folded into its consumer, materialise it
+    if (ln_ok && c.n_layers > 0) {
+      Step st;
+      st.name = "enc.ln2_final";
+      st.tag = "add_layernorm";
+      const float *g2 = v->enc[c.n_layers - 1].g2, *b2 = v->enc[c.n_layers - 1].b2;
+      st.run = [=](hipStream_t q) {
+        float* o = x;
+        return piper_hip_add_layernorm_f32(ctx, y, nullptr, g2, b2, NB, H, T, 1e-5f, &o, (piper_hip_stream)q);
+      };
+      s.steps.push_back(st);
+    }
+    return build_duration_predictor(v, s, ar, x, T, NB);
+  }
   if (ln_ok && c.n_layers > 0)
     add_conv(v, s, "enc.ln2_proj", v->proj, with_ln(plain(y, stats, H, 2 * I, T, lensT), st2, v->enc[c.n_layers - 1].g2, v->enc[c.n_layers - 1].b2, x), T);
   else
@@ -1046,7 +1128,7 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
     const unsigned* rngd = s.rng;
     st.run = [=](hipStream_t q) {
       const int grid = (int)std::min<int64_t>(ceil_div((int64_t)I * F, kBlock), 4096);
-      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid, NB), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd, rngd);
+      hipLaunchKernelGGL(expand_noise_kernel, dim3(grid, NB), dim3(kBlock), 0, q, stats, f2i, nz, zp, zp_tap, I, T, F, nsd, rngd, lensF);
       return PIPER_HIP_OK;
     };
     // path expansion counted as the reference's two MatMuls mm(1,F,192,T)
@@ -1280,6 +1362,88 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, bool gen_o
   return PIPER_HIP_OK;
 }
 
+int build_duration_predictor(piper_hip_voice* v, Slot& s, Arena& ar, const float* x, int T, int NB) {
+  const piper_hip_voice_config& c = v->cfg;
+  piper_hip_ctx* ctx = v->ctx;
+  const int H = c.hidden, nbins = c.dp_bins, K = c.dp_kernel;
+  const size_t B = (size_t)NB;
+  if (!c.dp_present || v->dp.empty()) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice has no duration predictor (dp_present = 0): supply durations");
+  if (!dds_layer_eligible(H, K)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "duration predictor: hidden %d / kernel %d not covered", H, K);
+  float* a0 = ar.f32(B * H * T);
+  float* a1 = ar.f32(B * H * T);
+  float* cond = ar.f32(B * H * T);                  // the predictor's conditioning x for the flows
+  float* hsp = ar.f32(B * (size_t)(3 * nbins - 1) * T);
+  float* z = ar.f32(B * 2 * T);
+  float* logw = ar.f32(B * T);
+  s.dp_noise = ar.f32(B * 2 * T);
+  s.dp_scalars = ar.raw(dp_scalars_bytes(NB));
+  s.dp_dur = (int32_t*)ar.raw(B * T * sizeof(int32_t));
+  if (ar.rc) return ar.rc;
+  const int* lensT = s.lensT;
+  auto conv_k1 = [&](const std::string& name, const ConvW& w, const float* in, int64_t in_bs, float* out, const float* res) {
+    ConvArgs a;
+    a.x = in; a.y = out; a.N = NB; a.Lin = T; a.Lout = T; a.x_batch_stride = in_bs; a.y_batch_stride = (int64_t)w.Cout * T; a.y_len = T;
+    a.len_ptr = lensT; a.res = res;
+    add_conv(v, s, name, w, a, T);
+  };
+  auto dds_stack = [&](const std::string& name, const std::vector<piper_hip_voice::DdsLayer>& layers, float* cur, float* other) {
+    // layer i: cur → other, then swap; returns where the result lives
+    int dil = 1;
+    for (size_t i = 0; i < layers.size(); i++) {
+      const auto& L = layers[i];
+      Step st;
+      st.name = name + ".dds" + std::to_string(i);
+      st.tag = "dds_layer";
+      const float *src = cur, *dw_w = L.dw_w, *dw_b = L.dw_b, *g1 = L.g1, *b1 = L.b1, *pw = L.pw.w16, *pwb = L.pw.bias, *g2 = L.g2, *b2 = L.b2;
+      float* dst = other;
+      const int steps = (int)(packed_conv_floats(H, H, 1, 16) / ((size_t)ceil_div(H, 16) * 64));
+      const int d2 = dil;
+      st.run = [=](hipStream_t q) { return launch_dds_layer(ctx, q, src, dw_w, dw_b, g1, b1, pw, pwb, g2, b2, dst, NB, H, T, K, d2, steps, lensT, 1e-5f); };
+      st.flops = NB * (conv_flops(H, H, 1, T) + conv_flops(H, 1, K, T));
+      st.bytes = NB * 4.0 * (2.0 * H * T + (double)H * H);
+      s.steps.push_back(st);
+      std::swap(cur, other);
+      dil *= K;
+    }
+    return cur;
+  };
+  // x → pre → DDSConv → proj = the conditioning of every flow
+  conv_k1("dp.pre", v->dp[0].pre, x, (int64_t)H * T, a0, nullptr);
+  float* r = dds_stack("dp", v->dp[0].dds, a0, a1);
+  conv_k1("dp.proj", v->dp[0].proj, r, (int64_t)H * T, cond, nullptr);
+  {
+    Step st;
+    st.name = "dp.init_latent";
+    const float* nz = s.dp_noise;
+    const void* sc = s.dp_scalars;
+    st.run = [=](hipStream_t q) { return launch_dp_init(q, nz, sc, z, NB, T, lensT); };
+    s.steps.push_back(st);
+  }
+  for (size_t b = 1; b < v->dp.size(); b++) {
+    const auto& Bk = v->dp[b];
+    const std::string p = "dp.flow" + std::to_string(Bk.flow);
+    conv_k1(p + ".pre_add_cond", Bk.pre, z, (int64_t)2 * T, a0, cond);  // h = pre(z0) + g: the DDSConv's `x + g`
+    float* hr = dds_stack(p, Bk.dds, a0, a1);
+    conv_k1(p + ".proj", Bk.proj, hr, (int64_t)H * T, hsp, nullptr);
+    Step st;
+    st.name = p + ".spline_flip";
+    const float tb = c.dp_tail_bound, fc = (float)H;
+    st.run = [=](hipStream_t q) { return launch_dp_spline(q, hsp, z, NB, T, nbins, tb, fc, lensT); };
+    s.steps.push_back(st);
+  }
+  {
+    Step st;
+    st.name = "dp.affine_exp_ceil";
+    const float *m = v->dp_m, *lg = v->dp_logs;
+    const void* sc = s.dp_scalars;
+    int32_t* dur = s.dp_dur;
+    st.run = [=](hipStream_t q) { return launch_dp_final(q, z, m, lg, sc, logw, dur, NB, T, lensT); };
+    s.steps.push_back(st);
+  }
+  s.taps["logw"] = {logw, 1, T, 0, (size_t)T};
+  return PIPER_HIP_OK;
+}
+
 int run_schedule(Slot& s, hipStream_t q, bool parallel) {
   for (auto& st : s.steps) {
     if (st.kind == Step::FORK) {
@@ -1322,9 +1486,14 @@ int slot_init(piper_hip_voice* v, Slot& s) {
 
 int check_utt(const piper_hip_voice* v, const piper_hip_utterance* u, int64_t* F_out) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
-  if (!u || !u->phoneme_ids || !u->durations) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: null ids/durations");
+  if (!u || !u->phoneme_ids) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: null ids");
   if (u->t < 1) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: need at least one phoneme id");
   if (u->t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: %d ids exceeds the 4096 cap (PiperCLI.swift:394)", u->t);
+  if (!u->durations) {  // to be predicted: the frame count is not known yet
+    if (!v->cfg.dp_present) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: durations are NULL and the voice has no duration predictor");
+    *F_out = -1;
+    return PIPER_HIP_OK;
+  }
   int64_t F = 0;
   for (int i = 0; i < u->t; i++) {
     if (u->durations[i] < 0) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: negative duration");
@@ -1489,6 +1658,7 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
 PH_EXPORT int64_t piper_hip_voice_num_samples(const piper_hip_voice* v, const piper_hip_utterance* u) {
   int64_t F = 0;
   if (check_utt(v, u, &F)) return -1;
+  if (F < 0) return -2;
   return F * v->hop;
 }
 
@@ -1534,7 +1704,7 @@ int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** ou
   std::unique_ptr<Slot> np(new Slot());
   int rc = slot_init(v, *np);
   if (rc) { slot_release(v, *np, true); return rc; }
-  if ((rc = build_schedule(v, *np, Tb, Fb, NB, kind == 1))) { slot_release(v, *np, true); return rc; }
+  if ((rc = build_schedule(v, *np, Tb, Fb, NB, kind))) { slot_release(v, *np, true); return rc; }
   Slot& s = *np;
   // the validation pass and the capture run on whatever the arena holds: give the length arrays legal values first
   {
@@ -1545,6 +1715,8 @@ int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** ou
     if (e == hipSuccess && s.ids) e = hipMemsetAsync(s.ids, 0, (size_t)NB * Tb * sizeof(int64_t), s.stream);
     if (e == hipSuccess && s.frame2id) e = hipMemsetAsync(s.frame2id, 0, (size_t)NB * Fb * sizeof(int32_t), s.stream);
     if (e == hipSuccess && s.rng) e = hipMemsetAsync(s.rng, 0, (size_t)NB * 2 * sizeof(unsigned), s.stream);
+    if (e == hipSuccess && s.dp_scalars) e = hipMemsetAsync(s.dp_scalars, 0, dp_scalars_bytes(NB), s.stream);
+    if (e == hipSuccess && s.dp_noise) e = hipMemsetAsync(s.dp_noise, 0, (size_t)NB * 2 * Tb * sizeof(float), s.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
     if (e != hipSuccess) { slot_release(v, s, true); PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: arena initialisation failed: %s", hipGetErrorString(e)); }
   }
@@ -1599,6 +1771,35 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   int Tmax = 0, rc;
   int64_t Fmax = 0;
   std::vector<int> hT(n), hF(n);
+  // utterances without durations: run the text encoder + duration predictor first (its own cached plan), then continue with
+  // the predicted frames per id exactly as if the caller had supplied them
+  std::vector<piper_hip_utterance> resolved;
+  std::vector<int32_t> predicted;
+  {
+    bool any_null = false;
+    for (int b = 0; b < n; b++) any_null = any_null || (utts[b].phoneme_ids && !utts[b].durations);
+    if (any_null) {
+      int64_t total = 0;
+      for (int b = 0; b < n; b++) {
+        if (utts[b].t < 1 || utts[b].t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance %d: bad phoneme count", b);
+        total += utts[b].t;
+      }
+      predicted.resize((size_t)total);
+      if ((rc = piper_hip_voice_predict_durations(v, utts, n, predicted.data(), nullptr, (int)total))) return rc;
+      resolved.assign(utts, utts + n);
+      int64_t off = 0;
+      for (int b = 0; b < n; b++) {
+        if (!resolved[b].durations) {
+          int64_t F = 0;
+          for (int t = 0; t < utts[b].t; t++) F += predicted[off + t];
+          if (F < 1) predicted[off] = 1;  // Piper: y_lengths = clamp_min(Σ w_ceil, 1)
+          resolved[b].durations = predicted.data() + off;
+        }
+        off += utts[b].t;
+      }
+      utts = resolved.data();
+    }
+  }
   for (int b = 0; b < n; b++) {
     int64_t Fb = 0;
     if ((rc = check_utt(v, &utts[b], &Fb))) return rc;
@@ -1646,9 +1847,11 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   }
   s.h_noise_scale.resize(n);
   s.h_rng.resize(2 * (size_t)n);
+  s.h_dur.clear();
   for (int b = 0; b < n; b++) {
     const piper_hip_utterance* u = &utts[b];
     const int Tb = hT[b], Fb = hF[b];
+    s.h_dur.insert(s.h_dur.end(), u->durations, u->durations + Tb);
     s.h_lens[b] = Tb;
     s.h_lens[n + b] = Fb;
     s.h_rng[2 * b] = (!u->noise && u->noise_mode == PIPER_HIP_NOISE_DEVICE) ? 1u : 0u;
@@ -1676,6 +1879,92 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // noise / scalars come from caller memory
   s.timed = false;
   return slot;
+}
+
+PH_EXPORT int piper_hip_voice_predict_durations(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out,
+                                                int max_entries) {
+  if (!v || !utts || !durations_out) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
+  if (!v->cfg.dp_present) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice has no duration predictor (dp_present = 0)");
+  int Tmax = 0;
+  int64_t total = 0;
+  for (int b = 0; b < n; b++) {
+    if (!utts[b].phoneme_ids) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: null ids", b);
+    if (utts[b].t < 1 || utts[b].t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance %d: %d ids outside [1,4096]", b, utts[b].t);
+    if (utts[b].noise_mode != PIPER_HIP_NOISE_INJECTED && utts[b].noise_mode != PIPER_HIP_NOISE_DEVICE)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: unknown noise_mode %d", b, utts[b].noise_mode);
+    Tmax = std::max(Tmax, utts[b].t);
+    total += utts[b].t;
+  }
+  if (max_entries < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "predict_durations: output holds %d < %lld entries", max_entries, (long long)total);
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  const int T = bucket_t(Tmax);
+  Slot* pl = nullptr;
+  bool built = false;
+  int rc = acquire_plan(v, 2, T, 16, n, &pl, &built);
+  if (rc) return rc;
+  Slot& s = *pl;
+  s.in_use = true;
+  s.last_use = ++v->use_clock;
+  std::vector<int64_t> ids((size_t)n * T, 0);
+  std::vector<int> lens(n);
+  std::vector<float> nz((size_t)n * 2 * T, 0.0f);
+  std::vector<char> sc(dp_scalars_bytes(n));
+  for (int b = 0; b < n; b++) {
+    const piper_hip_utterance& u = utts[b];
+    memcpy(ids.data() + (size_t)b * T, u.phoneme_ids, (size_t)u.t * sizeof(int64_t));
+    lens[b] = u.t;
+    if (u.dp_noise)
+      for (int r = 0; r < 2; r++) memcpy(nz.data() + ((size_t)b * 2 + r) * T, u.dp_noise + (size_t)r * u.t, (size_t)u.t * sizeof(float));
+    // device mode draws element (row, t) of the item's OWN [1, 2, T_b] tensor: the kernel indexes the bucket row, so the draw
+    // index must be remapped when T_b < T — done by generating on the host side of the index: see dp_init_kernel (uses T).
+    dp_scalars_fill(sc.data(), b, u.noise_w, u.length_scale == 0.0f ? 1.0f : u.length_scale,
+                    (!u.dp_noise && u.noise_mode == PIPER_HIP_NOISE_DEVICE) ? 1u : 0u, u.seed);
+  }
+  hipError_t e = hipMemcpyAsync(s.ids, ids.data(), ids.size() * sizeof(int64_t), hipMemcpyHostToDevice, s.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(s.lensT, lens.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(s.dp_noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice, s.stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(s.dp_scalars, sc.data(), sc.size(), hipMemcpyHostToDevice, s.stream);
+  if (e == hipSuccess) e = hipGraphLaunch(s.exec, s.stream);
+  std::vector<int32_t> dur((size_t)n * T);
+  std::vector<float> lw(logw_out ? (size_t)n * T : 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(dur.data(), s.dp_dur, dur.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
+  if (e == hipSuccess && logw_out) e = hipMemcpyAsync(lw.data(), s.taps["logw"].p, lw.size() * sizeof(float), hipMemcpyDeviceToHost, s.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+  s.in_use = false;
+  evict_idle_plans(v);
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "predict_durations: %s", hipGetErrorString(e));
+  int64_t off = 0;
+  for (int b = 0; b < n; b++) {
+    memcpy(durations_out + off, dur.data() + (size_t)b * T, (size_t)utts[b].t * sizeof(int32_t));
+    if (logw_out) memcpy(logw_out + off, lw.data() + (size_t)b * T, (size_t)utts[b].t * sizeof(float));
+    off += utts[b].t;
+  }
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_prepared_samples(const piper_hip_voice* v, int slot, int64_t* per_item, int max_items, int64_t* total) {
+  const Slot* p = slot_plan(v, slot);
+  if (!p) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  int64_t sum = 0;
+  for (int b = 0; b < p->NB; b++) {
+    const int64_t nb = (int64_t)p->h_F[b] * v->hop;
+    if (per_item && b < max_items) per_item[b] = nb;
+    sum += nb;
+  }
+  if (total) *total = sum;
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_durations(const piper_hip_voice* v, int slot, int32_t* out, int max_entries, int* n_entries) {
+  const Slot* p = slot_plan(v, slot);
+  if (!p) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
+  if (n_entries) *n_entries = (int)p->h_dur.size();
+  if (out) {
+    if (max_entries < (int)p->h_dur.size()) PH_FAIL(PIPER_HIP_ERR_SHAPE, "durations: buffer too small");
+    memcpy(out, p->h_dur.data(), p->h_dur.size() * sizeof(int32_t));
+  }
+  return PIPER_HIP_OK;
 }
 
 PH_EXPORT int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, int slot) {

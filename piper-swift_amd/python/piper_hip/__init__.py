@@ -105,7 +105,8 @@ class PiperJsonInfo(C.Structure):
 
 class Utterance(C.Structure):
     _fields_ = [("phoneme_ids", c_i64p), ("t", C.c_int32), ("durations", c_i32p), ("noise", c_f32p),
-                ("noise_scale", C.c_float), ("noise_mode", C.c_int32), ("seed", C.c_uint32)]
+                ("noise_scale", C.c_float), ("noise_mode", C.c_int32), ("seed", C.c_uint32), ("length_scale", C.c_float),
+                ("noise_w", C.c_float), ("dp_noise", c_f32p)]
 
 
 NOISE_MODES = {"injected": 0, "device": 1}
@@ -196,6 +197,9 @@ _PROTOS = {
     "piper_hip_voice_destroy": (None, [c_vp]),
     "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
     "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
+    "piper_hip_voice_predict_durations": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, c_i32p, c_f32p, C.c_int]),
+    "piper_hip_voice_prepared_samples": (C.c_int, [c_vp, C.c_int, c_i64p, C.c_int, c_i64p]),
+    "piper_hip_voice_durations": (C.c_int, [c_vp, C.c_int, c_i32p, C.c_int, C.POINTER(C.c_int)]),
     "piper_hip_voice_prepare_batch": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
     "piper_hip_voice_batch_size": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_plan_info": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -707,34 +711,74 @@ class HipRuntime:
         _check(self.lib.piper_hip_voice_set_precision(self.voice, int(code)))
         self._keep.clear()  # prepared slots are dropped by the library
 
-    def _utt(self, ids, durations, noise, noise_scale, noise_mode="injected", seed=1234):
+    def _utt(self, ids, durations, noise, noise_scale, noise_mode="injected", seed=1234, length_scale=1.0, noise_w=0.8, dp_noise=None):
+        """durations None ⇒ predicted on the device (duration predictor) from length_scale / noise_w / dp_noise."""
         ids = np.ascontiguousarray(ids, np.int64)
-        dur = np.ascontiguousarray(durations, np.int32)
+        dur = None if durations is None else np.ascontiguousarray(durations, np.int32)
         nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
-        u = Utterance(ids.ctypes.data_as(c_i64p), len(ids), dur.ctypes.data_as(c_i32p),
+        dpn = None if dp_noise is None else np.ascontiguousarray(dp_noise, np.float32)
+        u = Utterance(ids.ctypes.data_as(c_i64p), len(ids), None if dur is None else dur.ctypes.data_as(c_i32p),
                       None if nz is None else nz.ctypes.data_as(c_f32p), float(noise_scale),
-                      NOISE_MODES.get(noise_mode, noise_mode), int(seed) & 0xFFFFFFFF)
-        return u, (ids, dur, nz)
+                      NOISE_MODES.get(noise_mode, noise_mode), int(seed) & 0xFFFFFFFF, float(length_scale), float(noise_w),
+                      None if dpn is None else dpn.ctypes.data_as(c_f32p))
+        return u, (ids, dur, nz, dpn)
 
     def num_samples(self, ids, durations):
         u, _k = self._utt(ids, durations, None, 0.0)
         return int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u)))
 
-    def synthesize(self, phonemeIDs, durations, noise=None, noiseScale=0.667):
-        u, _k = self._utt(phonemeIDs, durations, noise, noiseScale)
-        n = int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u)))
-        out = np.empty(max(n, 1), np.float32)
-        got = C.c_int64()
-        _check(self.lib.piper_hip_voice_synthesize(self.voice, C.byref(u), out.ctypes.data_as(c_f32p), n, C.byref(got)))
-        return out[:got.value]
+    def synthesize(self, phonemeIDs, durations=None, noise=None, noiseScale=0.667, lengthScale=1.0, noiseW=0.8, **kw):
+        """PiperMetalRuntime.synthesize(phonemeIDs:noiseScale:lengthScale:noiseW:); `durations` / `noise` / dp_noise are the
+        reference's `overrides`. Without durations the frames per id come from the voice's duration predictor."""
+        if durations is not None and not kw:  # the one-call C entry point
+            u, _k = self._utt(phonemeIDs, durations, noise, noiseScale)
+            n = int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u)))
+            out = np.empty(max(n, 1), np.float32)
+            got = C.c_int64()
+            _check(self.lib.piper_hip_voice_synthesize(self.voice, C.byref(u), out.ctypes.data_as(c_f32p), n, C.byref(got)))
+            self._keep.pop(0, None)
+            return out[:got.value]
+        self.prepare(0, phonemeIDs, durations, noise, noiseScale, length_scale=lengthScale, noise_w=noiseW, **kw)
+        self.launch(0)
+        return self.collect(0)
 
-    def prepare(self, slot, phonemeIDs, durations, noise=None, noiseScale=0.667, noise_mode="injected", seed=1234):
-        u, k = self._utt(phonemeIDs, durations, noise, noiseScale, noise_mode, seed)
-        self._keep[slot] = (k, int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(u))))
+    def prepare(self, slot, phonemeIDs, durations=None, noise=None, noiseScale=0.667, noise_mode="injected", seed=1234, length_scale=1.0,
+                noise_w=0.8, dp_noise=None):
+        u, k = self._utt(phonemeIDs, durations, noise, noiseScale, noise_mode, seed, length_scale, noise_w, dp_noise)
         rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
         if rc < 0:
             _check(rc)
+        tot = C.c_int64()
+        _check(self.lib.piper_hip_voice_prepared_samples(self.voice, slot, None, 0, C.byref(tot)))
+        self._keep[slot] = (k, int(tot.value))
         return rc
+
+    def durations(self, slot):
+        """Frames per id the prepared slot uses (supplied or predicted), items back to back."""
+        n = C.c_int()
+        _check(self.lib.piper_hip_voice_durations(self.voice, slot, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.int32)
+        _check(self.lib.piper_hip_voice_durations(self.voice, slot, out.ctypes.data_as(c_i32p), n.value, C.byref(n)))
+        return out
+
+    def predict_durations(self, utterances, noise_w=0.8, length_scale=1.0, noise_mode="injected", seed=1234):
+        """utterances: list of (phonemeIDs, dp_noise-or-None). Returns (durations, logw) lists per utterance."""
+        n = len(utterances)
+        arr = (Utterance * n)()
+        keep = []
+        for i, (ids, dpn) in enumerate(utterances):
+            u, k = self._utt(ids, None, None, 0.0, noise_mode, seed, length_scale, noise_w, dpn)
+            arr[i] = u
+            keep.append(k)
+        total = sum(len(u[0]) for u in utterances)
+        dur = np.empty(total, np.int32)
+        lw = np.empty(total, np.float32)
+        _check(self.lib.piper_hip_voice_predict_durations(self.voice, arr, n, dur.ctypes.data_as(c_i32p), lw.ctypes.data_as(c_f32p), total))
+        outs, off = [], 0
+        for ids, _ in utterances:
+            outs.append((dur[off:off + len(ids)].copy(), lw[off:off + len(ids)].copy()))
+            off += len(ids)
+        return outs
 
     def synthesize_stream(self, phonemeIDs, durations, noise=None, noiseScale=0.667, chunkFrames=64, slot=0):
         """Generator of waveform chunks (PiperMetalRuntime.synthesizeStream): encoder + flow once, generator per window."""
@@ -760,11 +804,12 @@ class HipRuntime:
             u, k = self._utt(ids, dur, noise, noiseScale)
             arr[i] = u
             keep.append(k)
-            total += int(self.lib.piper_hip_voice_num_samples(self.voice, C.byref(arr[i])))
-        self._keep[slot] = (keep, total)
         rc = self.lib.piper_hip_voice_prepare_batch(self.voice, arr, n, slot)
         if rc < 0:
             _check(rc)
+        tot = C.c_int64()
+        _check(self.lib.piper_hip_voice_prepared_samples(self.voice, slot, None, 0, C.byref(tot)))
+        self._keep[slot] = (keep, int(tot.value))
         return rc
 
     def plan_info(self, slot):

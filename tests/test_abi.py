@@ -55,8 +55,11 @@ def test_presets_and_blob_layout():
     for e in lay:
         assert e["offset"] == off and e["count"] == int(np.prod(e["shape"]))
         off += e["count"]
-    assert off == ph.blob_floats(m) == 15095296
-    assert ph.blob_floats(h) == 27759744
+    assert off == ph.blob_floats(m) == 15650459
+    m.dp_present = 0  # without the duration predictor's tensors (appended at the end: earlier offsets do not move)
+    assert ph.blob_floats(m) == 15095296
+    assert [e["name"] for e in ph.blob_layout(m)] == names[:len(ph.blob_layout(m))]
+    assert ph.blob_floats(h) == 28314907  # 27 759 744 + the duration predictor
 
 
 def test_synthetic_blob_matches_numpy_generator():

@@ -1,0 +1,191 @@
+"""The stochastic duration predictor (Piper `dp`: DDSConv stacks, reverse ConvFlows with the inverse rational-quadratic
+spline, ElementwiseAffine; exp · length_scale · ceil). Reference call site: PiperMetalRuntime.synthesize runs the whole graph,
+PiperMetalGraph.swift:1124 lists the ops (Erf, Softplus, Softmax, CumSum, GatherND, ScatterND, Where …) this restates.
+
+CPU: the C oracle against tests/golden/dp.npz (torch restatement, itself 0.0 from transformers' VitsStochasticDurationPredictor).
+GPU: piper_hip_voice_predict_durations and prepare(durations = NULL) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import katdata as kd
+import oracle as orc
+import piper_hip as ph
+from conftest import OP_TOL, WAVE_TOL, assert_close
+
+SD = kd.case_seed("dp", 0)
+LOGW_TOL = 2e-4  # |Δ logw|: the spline's quadratic root amplifies fp32 summation-order noise of the 1×1 convs ≈ 20×
+
+
+def dp_noise(fct):
+    return kd.sym(SD + fct, (2, 14 * fct), 1.7320508)
+
+
+def ceil_safe(logw, length_scale=1.0, margin=2e-3):
+    """Mask of positions whose exp(logw)·length_scale is not within `margin` of an integer (ceil is discontinuous there)."""
+    w = np.exp(np.asarray(logw, np.float64)) * length_scale
+    return np.abs(w - np.round(w)) > margin
+
+
+@pytest.mark.parametrize("quality", ["medium", "high"])
+@pytest.mark.parametrize("fct", [1, 3])
+@pytest.mark.parametrize("nw", [0.8, 0.0])
+def test_oracle_duration_predictor_vs_golden(quality, fct, nw, voices):
+    cfg, blob = voices[quality]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dp.npz"))
+    ids = kd.FIXTURE_IDS * fct
+    enc, _ = orc.text_encoder(cfg, blob, ids)
+    lw = orc.duration_logw(cfg, blob, enc, dp_noise(fct), nw)
+    ref = g[f"{quality}.f{fct}.nw{nw}.logw"]
+    assert np.abs(lw - ref).max() <= LOGW_TOL, np.abs(lw - ref).max()
+    d = orc.durations_from_logw(lw, 1.0)
+    ok = ceil_safe(ref)
+    assert ok.sum() >= ok.size - 2
+    assert np.array_equal(d[ok], g[f"{quality}.f{fct}.nw{nw}.dur"].astype(np.int32)[ok])
+
+
+def test_oracle_durations_length_scale_and_floor():
+    lw = np.array([-30.0, 0.0, np.log(2.0), np.log(2.5), 1.0], np.float32)
+    assert orc.durations_from_logw(lw, 1.0).tolist() == [1, 1, 2, 3, 3]  # ceil(e^-30) = 1, ceil(1) = 1
+    assert orc.durations_from_logw(lw, 2.0).tolist() == [1, 2, 4, 5, 6]
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def rts(backend, voices):
+    out = {}
+    for q in ("medium", "high"):
+        cfg, blob = voices[q]
+        out[q] = ph.HipRuntime(backend, cfg, blob)
+    yield out
+    for r in out.values():
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", ["medium", "high"])
+@pytest.mark.parametrize("fct,nw,ls", [(1, 0.8, 1.0), (3, 0.8, 1.3), (3, 0.0, 1.0), (8, 0.8, 0.9), (64, 0.8, 1.0)])
+def test_predict_durations_vs_oracle(quality, fct, nw, ls, rts, voices):
+    cfg, blob = voices[quality]
+    ids = kd.FIXTURE_IDS * fct
+    nz = kd.sym(SD + fct, (2, len(ids)), 1.7320508)
+    enc, _ = orc.text_encoder(cfg, blob, ids)
+    lw_ref = orc.duration_logw(cfg, blob, enc, nz, nw)
+    d_ref = orc.durations_from_logw(lw_ref, ls)
+    (d, lw), = rts[quality].predict_durations([(ids, nz)], noise_w=nw, length_scale=ls)
+    err = np.abs(lw - lw_ref).max()
+    print(f"{quality} f{fct} nw={nw}: max|Δ logw| = {err:.2e}")
+    assert err <= LOGW_TOL, err
+    ok = ceil_safe(lw_ref, ls)
+    assert ok.sum() >= ok.size * 0.98
+    assert np.array_equal(d[ok], d_ref[ok])
+    assert np.all(np.abs(d - d_ref) <= 1)
+
+
+@pytest.mark.gpu
+def test_predict_durations_ragged_batch(rts, voices):
+    """Five utterances of different lengths in ONE predictor launch equal the one-by-one results exactly (same kernels, the
+    padding columns never enter a valid column's sums) and the oracle within LOGW_TOL."""
+    cfg, blob = voices["medium"]
+    rt = rts["medium"]
+    items = []
+    for i, n in enumerate((14, 5, 37, 1, 112)):
+        ids = (kd.FIXTURE_IDS * 8)[:n]
+        items.append((ids, kd.sym(SD + 50 + i, (2, n), 1.7320508)))
+    batch = rt.predict_durations(items, noise_w=0.8)
+    for (ids, nz), (d, lw) in zip(items, batch):
+        (d1, lw1), = rt.predict_durations([(ids, nz)], noise_w=0.8)
+        assert np.array_equal(d, d1)
+        assert_close(lw, lw1, 1e-6, f"ragged vs single, {len(ids)} ids")
+        enc, _ = orc.text_encoder(cfg, blob, ids)
+        assert np.abs(lw - orc.duration_logw(cfg, blob, enc, nz, 0.8)).max() <= LOGW_TOL
+
+
+@pytest.mark.gpu
+def test_predict_durations_device_noise(rts, voices):
+    """noise_mode DEVICE: the `dp` tensor is RandomNormalLike(seed) over [1, 2, T] drawn on the device — the oracle gets the
+    same tensor from orc_random_normal_like."""
+    cfg, blob = voices["medium"]
+    ids = kd.FIXTURE_IDS * 3
+    nz = orc.random_normal_like(2 * len(ids), 1234).reshape(2, -1)
+    enc, _ = orc.text_encoder(cfg, blob, ids)
+    lw_ref = orc.duration_logw(cfg, blob, enc, nz, 0.8)
+    (d, lw), = rts["medium"].predict_durations([(ids, None)], noise_w=0.8, noise_mode="device", seed=1234)
+    assert np.abs(lw - lw_ref).max() <= LOGW_TOL
+    (_, lw2), = rts["medium"].predict_durations([(ids, None)], noise_w=0.8, noise_mode="device", seed=99)
+    assert np.abs(lw2 - lw).max() > 1e-3  # another seed is another draw
+
+
+@pytest.mark.gpu
+def test_predict_durations_null_noise_is_deterministic_mean(rts, voices):
+    """Injected mode without a dp_noise tensor = zeros (the reference's deterministic override with noiseW = 0)."""
+    cfg, blob = voices["medium"]
+    ids = kd.FIXTURE_IDS
+    enc, _ = orc.text_encoder(cfg, blob, ids)
+    lw_ref = orc.duration_logw(cfg, blob, enc, None, 0.8)
+    (_, lw), = rts["medium"].predict_durations([(ids, None)], noise_w=0.8)
+    assert np.abs(lw - lw_ref).max() <= LOGW_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_synthesize_with_predicted_durations(quality, rts, voices):
+    """prepare(durations = NULL): the predictor's frames-per-id feed the expansion on the device; waveform against the oracle
+    run with the SAME durations (read back through piper_hip_voice_durations), which are themselves checked above."""
+    cfg, blob = voices[quality]
+    rt = rts[quality]
+    ids = kd.FIXTURE_IDS * 2
+    nz = kd.sym(SD + 70, (2, len(ids)), 1.7320508)
+    rt.prepare(1, ids, None, None, 0.667, length_scale=1.1, noise_w=0.8, dp_noise=nz, noise_mode="device", seed=4321)
+    dur = rt.durations(1)
+    assert dur.size == len(ids) and dur.min() >= 0 and dur.sum() >= 1
+    (d_pred, _), = rt.predict_durations([(ids, nz)], noise_w=0.8, length_scale=1.1)
+    assert np.array_equal(dur, d_pred)
+    rt.launch(1)
+    audio = rt.collect(1)
+    F = int(dur.sum())
+    assert audio.size == F * cfg.hop
+    noise = orc.random_normal_like(cfg.inter * F, 4321).reshape(cfg.inter, F)
+    ref = orc.synthesize(cfg, blob, ids, dur.tolist(), noise, 0.667)
+    assert_close(audio, ref, WAVE_TOL, f"{quality}: predicted durations, device noise")
+
+
+@pytest.mark.gpu
+def test_batch_mixes_supplied_and_predicted_durations(rts, voices):
+    cfg, blob = voices["medium"]
+    rt = rts["medium"]
+    ids_a, ids_b = kd.FIXTURE_IDS * 2, kd.FIXTURE_IDS
+    dur_a = [2] * len(ids_a)
+    na = kd.sym(SD + 80, (cfg.inter, sum(dur_a)), 1.7320508)
+    rt.prepare_batch(2, [(ids_a, dur_a, na), (ids_b, None, None)], 0.667)  # item b: predicted durations, zero z noise
+    dur = rt.durations(2)
+    assert dur[:len(ids_a)].tolist() == dur_a
+    db = dur[len(ids_a):]
+    (d_pred, _), = rt.predict_durations([(ids_b, None)], noise_w=0.8)
+    assert np.array_equal(db, d_pred)
+    rt.launch(2)
+    audio = rt.collect(2)
+    na_s, nb_s = sum(dur_a) * cfg.hop, int(db.sum()) * cfg.hop
+    assert audio.size == na_s + nb_s
+    assert_close(audio[:na_s], orc.synthesize(cfg, blob, ids_a, dur_a, na, 0.667), WAVE_TOL, "item a")
+    zb = np.zeros((cfg.inter, int(db.sum())), np.float32)
+    assert_close(audio[na_s:], orc.synthesize(cfg, blob, ids_b, db.tolist(), zb, 0.667), WAVE_TOL, "item b")
+
+
+@pytest.mark.gpu
+def test_voice_without_predictor_refuses(backend, voices):
+    cfg, blob = voices["medium"]
+    cfg2 = ph.voice_config("medium")
+    cfg2.dp_present = 0
+    n = ph.blob_floats(cfg2)
+    rt = ph.HipRuntime(backend, cfg2, blob[:n])
+    try:
+        with pytest.raises(ph.UnsupportedOp):
+            rt.predict_durations([(kd.FIXTURE_IDS, None)])
+        with pytest.raises(ph.UnsupportedOp):
+            rt.prepare(0, kd.FIXTURE_IDS, None)
+        a = rt.synthesize(kd.FIXTURE_IDS, [3] * 14, None, 0.667)  # supplied durations still work
+        assert a.size == 42 * cfg.hop
+    finally:
+        rt.close()

@@ -16,7 +16,8 @@ def layout_dicts(cfg):
 
 
 CFG_FIELDS = ["n_vocab", "hidden", "n_heads", "n_layers", "ffn", "ffn_kernel", "window", "inter", "n_flows", "wn_layers",
-              "wn_kernel", "up_initial", "n_ups", "resblock_type", "n_rb", "rb_n_dil", "sample_rate"]
+              "wn_kernel", "up_initial", "n_ups", "resblock_type", "n_rb", "rb_n_dil", "sample_rate", "dp_present", "dp_kernel",
+              "dp_dds_layers", "dp_n_flows", "dp_bins", "dp_tail_bound"]
 
 
 def same_config(a, b):

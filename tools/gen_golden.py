@@ -133,7 +133,20 @@ def main():
         mods["synth_ragged.audio"] = r["audio"].numpy().reshape(-1)
         mods["synth_ragged.z"] = r["z"].numpy().reshape(-1)
     np.savez_compressed(os.path.join(out_dir, "modules.npz"), **{k: np.ascontiguousarray(v, np.float32) for k, v in mods.items()})
-    for f in ("ops_kat.npz", "modules.npz"):
+    # stochastic duration predictor (torch restatement, cross-checked against transformers' VitsStochasticDurationPredictor)
+    dp = {}
+    with torch.no_grad():
+        sd = kd.case_seed("dp", 0)
+        for name, ref, cfg in (("medium", ref_m, cfg_m), ("high", ref_h, cfg_h)):
+            for fct in (1, 3):
+                ids = kd.FIXTURE_IDS * fct
+                nz = kd.sym(sd + fct, (2, len(ids)), 1.7320508)
+                for nw in (0.8, 0.0):
+                    d, lw = ref.durations(ids, nz, nw, 1.0)
+                    dp[f"{name}.f{fct}.nw{nw}.logw"] = lw.astype(np.float32)
+                    dp[f"{name}.f{fct}.nw{nw}.dur"] = d.astype(np.float32)
+    np.savez_compressed(os.path.join(out_dir, "dp.npz"), **{k: np.ascontiguousarray(v, np.float32) for k, v in dp.items()})
+    for f in ("ops_kat.npz", "modules.npz", "dp.npz"):
         print(f, os.path.getsize(os.path.join(out_dir, f)) // 1024, "KiB")
 
 
