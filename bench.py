@@ -31,6 +31,8 @@ FIXTURE_IDS = [1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2]  # bench/fixtur
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
+PROFILE_F32 = "r2_rocprof_summary.json"  # committed PMC passes of `python bench.py` (see profiles/README.md)
+PROFILE_BF16 = "r2_high_bf16_rocprof_summary.json"
 
 
 def utterance(factor, seed, inter=192):
@@ -166,6 +168,7 @@ def main():
     cfg = ph.voice_config(args.quality)
     n_floats = ph.blob_floats(cfg)
     bcast_ms = None
+    comm_info = None
     keep = []
     if distributed:
         import torch
@@ -187,6 +190,25 @@ def main():
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
         backend = ph.HipBackend(local_rank)
+        # the same broadcast once more through the library's own C-ABI (piper_hip_comm_* over rccl.h — what a host without
+        # torch.distributed would call); its result must equal what torch.distributed delivered
+        try:
+            idt = torch.zeros(ph.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ph.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            comm = ph.Comm(backend, idt.cpu().numpy().tobytes(), rank, world)
+            w2 = wbuf.clone() if rank == 0 else torch.zeros_like(wbuf)
+            torch.cuda.synchronize()
+            comm.barrier()
+            t0 = time.perf_counter()
+            comm.broadcast_f32(w2.data_ptr(), n_floats, 0)
+            c_ms = comm.max((time.perf_counter() - t0) * 1e3)
+            comm_info = {"world": comm.world, "broadcast_ms": round(c_ms, 3), "equals_torch_broadcast": bool(torch.equal(w2, wbuf))}
+            comm.close()
+            del w2
+        except Exception as e:  # reported, never fatal: the torch.distributed broadcast above already delivered the blob
+            comm_info = {"error": repr(e)}
         rt = ph.HipRuntime(backend, cfg, wbuf.data_ptr(), on_device=True)
         keep.append(wbuf)
     else:
@@ -208,6 +230,19 @@ def main():
     ids, dur, noise = utterance(args.factor, 1234 + rank, cfg.inter)
     n_samples = rt.num_samples(ids, dur)
     audio_sec = n_samples / sr
+    # host-side cost of a request: cold = first prepare of this bucket (schedule build + graph capture +
+    # instantiate), warm = the same bucket again (H2D of ids / durations / noise into the cached plan, nothing rebuilt)
+    a = time.perf_counter()
+    rt.prepare(0, ids, dur, noise, 0.667)
+    prepare_cold_ms = (time.perf_counter() - a) * 1e3
+    warm = []
+    for k in range(5):
+        i2 = ids[:len(ids) - k] if k else ids  # k ≠ 0: another true length inside the same (T, F) bucket
+        d2 = dur[:len(i2)]
+        a = time.perf_counter()
+        rt.prepare(0, i2, d2, noise[:, :sum(d2)], 0.667)
+        warm.append((time.perf_counter() - a) * 1e3)
+    plan0 = rt.plan_info(0)
     rt.prepare(0, ids, dur, noise, 0.667)
 
     def step():
@@ -249,12 +284,38 @@ def main():
                    "factor": args.factor, "phoneme_count": len(ids), "frames": int(sum(dur)), "samples": int(n_samples),
                    "sample_rate": sr, "parallelism": f"utterance-replicas x{world} (one-shot RCCL weight broadcast)"},
         "gpu_ms_mean": round(float(np.mean(gpu_ms)), 4),
+        "prepare_ms_cold": round(prepare_cold_ms, 3),
+        "prepare_ms_warm": round(float(np.median(warm)), 4),
+        "plan": {"bucket_ids": plan0["bucket_t"], "bucket_frames": plan0["bucket_f"]},
     }
+    # end to end for one request on a cached plan: ids / durations / noise on the HOST → audio on the HOST
+    e2e = []
+    for _ in range(min(20, args.steps)):
+        a = time.perf_counter()
+        rt.prepare(0, ids, dur, noise, 0.667)
+        rt.launch(0)
+        rt.collect(0)
+        e2e.append((time.perf_counter() - a) * 1e3)
+    out["end_to_end_ms"] = round(float(np.median(e2e)), 4)
+    if cfg.dp_present:  # the same with the frames per id PREDICTED on the device (duration predictor + one D2H of T int32)
+        dpn = np.zeros((2, len(ids)), np.float32)
+        rt.prepare(1, ids, None, None, 0.667, noise_mode="device", dp_noise=dpn)
+        rt.launch(1); rt.collect(1)
+        e2p = []
+        for _ in range(min(20, args.steps)):
+            a = time.perf_counter()
+            rt.prepare(1, ids, None, None, 0.667, noise_mode="device", dp_noise=dpn)
+            rt.launch(1)
+            au = rt.collect(1)
+            e2p.append((time.perf_counter() - a) * 1e3)
+        out["end_to_end_predicted_durations"] = {"ms": round(float(np.median(e2p)), 4), "samples": int(au.size),
+                                                 "note": "duration predictor + device RandomNormalLike; no host-supplied tensors but the ids"}
     if bcast_ms is not None:
         import torch.distributed as dist
         out["weight_broadcast_ms"] = round(bcast_ms, 3)
         out["weight_blob_mb"] = round(n_floats * 4 / 1e6, 1)
         out["world_size_reported"] = dist.get_world_size()  # what RCCL's communicator says, not what --gpus asked for
+        out["piper_hip_comm"] = comm_info
 
     # ---- BASELINE configs[3]: the 32 mixed-length utterances, LPT-sharded over the ranks (all 32 on one GPU when N = 1).
     # EVERY rank runs its shard inside the same barrier bracket; the batch time is the MAX over ranks.
@@ -296,6 +357,30 @@ def main():
                    "per_rank": rows,
                    "note": "32 mixed-length utterances (factors 1..16), LPT-sharded over ranks, one prepare_batch schedule per shape "
                            "per rank, all ranks inside one barrier bracket, MAX over ranks"}
+        # the same shard as ≤ 2 RAGGED launches per rank (longest half / shortest half; per-item lengths on the device)
+        order = sorted(mine, key=lambda i: -factors[i])
+        halves = [h for h in (order[:(len(order) + 1) // 2], order[(len(order) + 1) // 2:]) if h]
+        for sl, idxs in enumerate(halves):
+            rt.prepare_batch(8 + sl, [utterance(factors[i], 3000 + 17 * factors[i] + i, cfg.inter) for i in idxs], 0.667)
+
+        def run_ragged():
+            for sl in range(len(halves)):
+                rt.launch(8 + sl)
+            for sl in range(len(halves)):
+                rt.collect(8 + sl, want_audio=False)
+        run_ragged()
+        barrier()
+        a = time.perf_counter()
+        for _ in range(reps):
+            run_ragged()
+        barrier()
+        dt2 = (time.perf_counter() - a) / reps
+        if distributed:
+            dt2 = phd.max_over_ranks(dt2, device="cuda")
+        batch32["ragged_2_launches"] = {"launches_per_rank": len(halves), "ms_per_batch": round(dt2 * 1e3, 3),
+                                        "utterances_per_sec": round(32 / dt2, 1), "audio_sec_per_wall_sec": round(tot_audio / dt2, 1),
+                                        "note": "each rank's shard as two ragged prepare_batch launches (bucket = longest item; "
+                                                "shorter items are masked by their true lengths on the device)"}
         rt.prepare(0, ids, dur, noise, 0.667)  # slot 0 back to the headline utterance
 
     if rank == 0:
@@ -322,9 +407,9 @@ def main():
                     n = sum(f["launches"] for f in fam)
                     return sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None
                 if args.factor == 8 and args.quality == "medium" and not bf16:
-                    traffic = per_launch("r1c_rocprof_summary.json", ("conv_stream_kernel", "conv_win_kernel"))
+                    traffic = per_launch(PROFILE_F32, ("conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel"))
                 elif args.factor == 8 and args.quality == "high" and bf16:
-                    traffic = per_launch("r1c_high_bf16_rocprof_summary.json", ("conv_bf16_kernel",))
+                    traffic = per_launch(PROFILE_BF16, ("conv_bf16_kernel",))
             except Exception:
                 pass
             out["roofline"] = {
@@ -333,7 +418,7 @@ def main():
                            "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_stream_kernel for short rows + conv_win_kernel for the generator long rows; all of their launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r1c*_rocprof_summary.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                "traffic_note": f"HBM bytes per launch from profiles/{PROFILE_BF16 if bf16 else PROFILE_F32}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; algorithmic bytes per launch "
                                 f"= {m_by / max(1, n_l) / 1e6:.2f} MB",
                 "timing": "HIP events around a graph replay of only these launches (30 replays)",

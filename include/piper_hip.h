@@ -47,6 +47,7 @@ enum {
 
 typedef struct piper_hip_ctx piper_hip_ctx;     /* MetalBackend + MetalContext (device, queue, pipelines) */
 typedef struct piper_hip_voice piper_hip_voice; /* a loaded voice: weights resident + static schedule */
+typedef struct piper_hip_comm piper_hip_comm;   /* an RCCL communicator: one rank (= one GPU, one process) of a node */
 typedef void* piper_hip_stream;                 /* hipStream_t; stands in for MTLCommandBuffer? */
 
 /* Thread-local description of the last failure on this thread ("" if none). */
@@ -466,6 +467,25 @@ int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, piper_hip_k
  * overhead; flops/bytes are the algorithmic totals of the subset (SURVEY.md Appendix A recipe). */
 int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const char* name_filter, int iters, double* avg_launch_us,
                                 int* n_launches, double* flops, double* bytes);
+
+/* ---- multi-GPU: the path's one collective --------------------------------------------------------------------
+ * Utterances are independent, so N GPUs are N replicas of the voice, one process per GPU; the only exchange is the one-shot
+ * broadcast of the voice blob from the rank that parsed the .onnx (PiperMetalRuntime.init(modelPath:) does that parse once per
+ * process, PiperMetalGraph.swift:25-41). These wrap rccl.h so that a host without torch.distributed (the Swift CLI, a C++
+ * server) can do it: rank 0 calls comm_unique_id and hands the 128 bytes to the other ranks by any side channel (a file, a
+ * socket, an environment variable), every rank calls comm_create (collective), uploads / allocates n_floats on its GPU,
+ * calls comm_broadcast_f32 (collective, in place, returns when the data is there) and piper_hip_voice_create(on_device = 1).
+ * comm_max_f64 / comm_barrier are what a bench needs for the "MAX over ranks between two barriers" timing rule.
+ * RCCL is bound at run time: without librccl.so.1 these return PIPER_HIP_ERR_UNAVAILABLE and the rest of the library works. */
+#define PIPER_HIP_COMM_ID_BYTES 128
+int piper_hip_comm_unique_id(void* id_out /* PIPER_HIP_COMM_ID_BYTES */);
+int piper_hip_comm_create(piper_hip_ctx* ctx, const void* id, int rank, int world, piper_hip_comm** out);
+void piper_hip_comm_destroy(piper_hip_comm* c);
+int piper_hip_comm_rank(const piper_hip_comm* c);
+int piper_hip_comm_world(const piper_hip_comm* c); /* ncclCommCount: what the communicator says */
+int piper_hip_comm_broadcast_f32(piper_hip_comm* c, float* device_buf, size_t count, int root);
+int piper_hip_comm_max_f64(piper_hip_comm* c, double* value); /* in/out: all-reduce MAX of one double */
+int piper_hip_comm_barrier(piper_hip_comm* c);
 
 #ifdef __cplusplus
 }

@@ -196,6 +196,14 @@ _PROTOS = {
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
     "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
+    "piper_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "piper_hip_comm_create": (C.c_int, [c_vp, C.c_void_p, C.c_int, C.c_int, C.POINTER(c_vp)]),
+    "piper_hip_comm_destroy": (None, [c_vp]),
+    "piper_hip_comm_rank": (C.c_int, [c_vp]),
+    "piper_hip_comm_world": (C.c_int, [c_vp]),
+    "piper_hip_comm_broadcast_f32": (C.c_int, [c_vp, C.c_void_p, C.c_size_t, C.c_int]),
+    "piper_hip_comm_max_f64": (C.c_int, [c_vp, C.POINTER(C.c_double)]),
+    "piper_hip_comm_barrier": (C.c_int, [c_vp]),
     "piper_hip_voice_prepare": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int]),
     "piper_hip_voice_predict_durations": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, c_i32p, c_f32p, C.c_int]),
     "piper_hip_voice_prepared_samples": (C.c_int, [c_vp, C.c_int, c_i64p, C.c_int, c_i64p]),
@@ -600,6 +608,54 @@ def synthetic_blob(cfg, seed=1234):
     blob = np.empty(n, np.float32)
     _check(load_library().piper_hip_voice_synthetic_blob(C.byref(cfg), seed, blob.ctypes.data_as(c_f32p), n))
     return blob
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclUniqueId) made by ONE rank; every rank of the world passes the same bytes to Comm()."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().piper_hip_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """piper_hip_comm_*: an RCCL communicator for the one-shot voice-blob broadcast (and the bench's MAX / barrier)."""
+
+    def __init__(self, backend, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.lib = backend.lib
+        h = c_vp()
+        _check(self.lib.piper_hip_comm_create(backend.ctx, C.c_char_p(unique_id), int(rank), int(world), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.piper_hip_comm_destroy(self.h)
+            self.h = None
+
+    @property
+    def rank(self):
+        return self.lib.piper_hip_comm_rank(self.h)
+
+    @property
+    def world(self):
+        return self.lib.piper_hip_comm_world(self.h)
+
+    def broadcast_f32(self, device_ptr, count, root=0):
+        ptr = _ptr(device_ptr)
+        if not isinstance(ptr, (C.c_void_p, C._Pointer)):
+            ptr = C.c_void_p(int(ptr))  # a raw address (torch.Tensor.data_ptr())
+        _check(self.lib.piper_hip_comm_broadcast_f32(self.h, ptr, int(count), int(root)))
+
+    def max(self, value):
+        v = C.c_double(float(value))
+        _check(self.lib.piper_hip_comm_max_f64(self.h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        _check(self.lib.piper_hip_comm_barrier(self.h))
 
 
 class OnnxModel:

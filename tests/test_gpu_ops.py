@@ -453,3 +453,26 @@ def test_convtranspose1d_long_rows_window_kernel(idx, backend):
     ref = orc.convtranspose1d(x, w, b, s, 1, pad, pad)
     assert shp == list(ref.shape)
     assert_close(dl(backend, out, shp), ref, OP_TOL, f"convT window case {idx}")
+
+
+def test_comm_single_rank_world(backend):
+    """piper_hip_comm_* over rccl.h with a world of one (all a one-GPU box can hold): the communicator reports its own size,
+    the in-place broadcast leaves the root's data untouched, MAX of one value is that value, barrier returns."""
+    uid = ph.comm_unique_id()
+    assert len(uid) == ph.COMM_ID_BYTES and any(uid)
+    c = ph.Comm(backend, uid, 0, 1)
+    try:
+        assert (c.rank, c.world) == (0, 1)
+        x = kd.sym(kd.case_seed("cfg", 77), (1 << 20,))
+        buf = backend.uploadFloat32(x)
+        c.broadcast_f32(buf, x.size, root=0)
+        assert np.array_equal(backend.downloadFloat32(buf), x)
+        assert c.max(3.25) == 3.25
+        c.barrier()
+        with pytest.raises(ph.InvalidArgument):
+            c.broadcast_f32(buf, x.size, root=1)
+        buf.free()
+    finally:
+        c.close()
+    with pytest.raises(ph.InvalidArgument):
+        ph.Comm(backend, uid, 2, 2)
