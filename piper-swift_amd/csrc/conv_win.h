@@ -58,4 +58,22 @@ bool convt_pipe_eligible(int Cin, int Cout, int K, int stride, int pad, int Lin)
 // convs[i].w4 must be the pipe image; same multi-conv contract as launch_conv_win_multi
 int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* convs, int count);
 
+// ---- rb_pair.hip: two chained ResBlock convs in one kernel, the intermediate kept in LDS (C ∈ {32, 64}, odd kernels)
+//   x1 = [res_a ? x : 0] + conv_a(lrelu(x)) + ba            (dilation dila, 'same' padding)
+//   y  = (res_b_x ? x : x1) + conv_b(lrelu(x1)) + bb        (dilation dilb)
+// ResBlock2 step pair: res_a = 1, res_b_x = 0. ResBlock1 pair (convs1[i], convs2[i]): res_a = 0, res_b_x = 1.
+struct RbPairArgs {
+  const float* x = nullptr;    // [N][C][L]
+  float* y = nullptr;          // [N][C][L]; must not alias x
+  const float *wa4 = nullptr, *ba = nullptr, *wb4 = nullptr, *bb = nullptr;  // conv_win fragment images + biases
+  int Ka = 1, dila = 1, Kb = 1, dilb = 1;
+  int res_a = 1, res_b_x = 0;
+  float alpha = 0.1f;          // LeakyReLU slope, 0 < α < 1
+  int N = 1, C = 0, L = 0;     // L % 4 == 0
+  const int* len_ptr = nullptr;  // true length of item n = len_ptr[n]·len_mul (bucketed schedules); null ⇒ L
+  int len_mul = 1;
+};
+bool rb_pair_eligible(int C, int Ka, int dila, int Kb, int dilb, int L);
+int launch_rb_pair_multi(piper_hip_ctx* ctx, hipStream_t s, const RbPairArgs* pairs, int count);  // ≤ kWinMulti pairs, same N, C, L
+
 }  // namespace ph

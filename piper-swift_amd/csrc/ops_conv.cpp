@@ -348,9 +348,41 @@ PH_EXPORT int piper_hip_hifigan_resblock_f32(piper_hip_ctx* ctx, int type, const
     a.w = w;
     return launch_conv_direct(ctx, ss.s, a);
   };
+  // two chained convs per launch (rb_pair.hip) where the geometry allows: ResBlock1 — every (convs1[i], convs2[i]) pair;
+  // ResBlock2 — steps (i, i+1)
+  static const bool no_pair = getenv("PIPER_HIP_NO_RB_PAIR") != nullptr;
+  auto pair = [&](const float* src, int ia, int da, int ib, int db, bool res_a, bool res_b_x, float* dst) -> int {
+    RbPairArgs pa;
+    float* pk[2];
+    for (int q = 0; q < 2; q++) {
+      int r = pool_floats(ctx, packed_conv_win_floats(C, C, K), &pk[q]);
+      if (r) return r;
+      defer_free(ctx, pk[q]);
+      pack_conv_weights_win(ss.s, weights[q ? ib : ia], C, C, K, pk[q]);
+    }
+    pa.x = src; pa.y = dst; pa.wa4 = pk[0]; pa.ba = biases[ia]; pa.wb4 = pk[1]; pa.bb = biases[ib];
+    pa.Ka = K; pa.dila = da; pa.Kb = K; pa.dilb = db; pa.res_a = res_a; pa.res_b_x = res_b_x; pa.alpha = lrelu_slope;
+    pa.N = (int)n; pa.C = C; pa.L = T;
+    return launch_rb_pair_multi(ctx, ss.s, &pa, 1);
+  };
+  const bool slope_ok = lrelu_slope > 0.0f && lrelu_slope < 1.0f;
+  auto next_buf = [&](bool last) { return last ? *out : (cur == tmp[0] ? tmp[1] : tmp[0]); };  // never the buffer being read
   for (int i = 0; i < n_dil; i++) {
-    float* dst = (i == n_dil - 1) ? *out : tmp[i & 1];
+    float* dst = next_buf(i == n_dil - 1);
     if (dilations[i] < 1) PH_FAIL(PIPER_HIP_ERR_SHAPE, "hifigan_resblock: dilation must be >= 1");
+    if (!no_pair && slope_ok && type == 1 && biases[2 * i] && biases[2 * i + 1] && rb_pair_eligible(C, K, dilations[i], K, 1, T)) {
+      if ((rc = pair(cur, 2 * i, dilations[i], 2 * i + 1, 1, false, true, dst))) return rc;
+      cur = dst;
+      continue;
+    }
+    if (!no_pair && slope_ok && type == 2 && i + 1 < n_dil && dilations[i + 1] >= 1 && biases[i] && biases[i + 1] &&
+        rb_pair_eligible(C, K, dilations[i], K, dilations[i + 1], T)) {
+      float* d2 = next_buf(i + 1 == n_dil - 1);
+      if ((rc = pair(cur, i, dilations[i], i + 1, dilations[i + 1], true, false, d2))) return rc;
+      cur = d2;
+      i++;
+      continue;
+    }
     if (type == 1) {
       if ((rc = conv(cur, weights[2 * i], biases[2 * i], dilations[i], nullptr, mid))) return rc;
       if ((rc = conv(mid, weights[2 * i + 1], biases[2 * i + 1], 1, cur, dst))) return rc;

@@ -894,12 +894,52 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       st.tag = "conv_mfma";
       s.steps.push_back(std::move(st));
     };
+    // two chained convs per launch, intermediate in LDS (rb_pair.hip): ResBlock1 — (convs1[di], convs2[di]); ResBlock2 —
+    // steps (di, di+1). PIPER_HIP_NO_RB_PAIR=1 keeps the conv-by-conv schedule (A/B).
+    static const bool no_pair = getenv("PIPER_HIP_NO_RB_PAIR") != nullptr;
+    auto add_pair = [&](const std::string& name, int ia, int ib, const int da[kWinMulti], const int db[kWinMulti], bool res_a, bool res_b_x,
+                        const float* const x[kWinMulti], float* const y[kWinMulti]) {
+      struct Pack { RbPairArgs a[kWinMulti]; } pk;
+      double fl = 0, by = 0;
+      for (int j = 0; j < kWinMulti; j++) {
+        const ConvW &wa = S.rb[j][ia], &wb = S.rb[j][ib];
+        if (no_pair || !wa.w4 || !wb.w4 || !wa.bias || !wb.bias || wa.Cin != wa.Cout || wa.Cin != wb.Cin || wb.Cin != wb.Cout ||
+            !rb_pair_eligible(wa.Cin, wa.K, da[j], wb.K, db[j], Lo))
+          return false;
+        RbPairArgs& a = pk.a[j];
+        a.x = x[j]; a.y = y[j]; a.wa4 = wa.w4; a.ba = wa.bias; a.wb4 = wb.w4; a.bb = wb.bias;
+        a.Ka = wa.K; a.dila = da[j]; a.Kb = wb.K; a.dilb = db[j]; a.res_a = res_a; a.res_b_x = res_b_x; a.alpha = 0.1f;
+        a.N = NB; a.C = wa.Cin; a.L = Lo; a.len_ptr = s.lensF; a.len_mul = Lo / F;
+        fl += NB * (conv_flops(wa.Cout, wa.Cin, wa.K, Lo) + conv_flops(wb.Cout, wb.Cin, wb.K, Lo));
+        by += NB * 4.0 * (2.0 * wa.Cin * (double)Lo + (double)wa.Cin * wa.Cin * (wa.K + wb.K) + 2.0 * wa.Cin);  // x in, y out, weights
+      }
+      Step st;
+      st.name = name;
+      st.run = [ctx, pk](hipStream_t q) { return launch_rb_pair_multi(ctx, q, pk.a, kWinMulti); };
+      st.flops = fl; st.bytes = by;
+      st.tag = "conv_mfma";
+      s.steps.push_back(std::move(st));
+      return true;
+    };
     for (int di = 0; di < c.rb_n_dil; di++) {
       float* dst[kWinMulti];
       int dil[kWinMulti], one[kWinMulti] = {1, 1, 1};
       const float* none[kWinMulti] = {nullptr, nullptr, nullptr};
-      for (int j = 0; j < kWinMulti; j++) { dst[j] = buf[j][di & 1]; dil[j] = c.rb_dilations[j][di]; }
+      for (int j = 0; j < kWinMulti; j++) { dst[j] = src[j] == buf[j][0] ? buf[j][1] : buf[j][0]; dil[j] = c.rb_dilations[j][di]; }  // never the buffer being read
       const std::string nm = p + "rb012.c" + std::to_string(di);
+      if (c.resblock_type == 1 && add_pair(nm + "ab_lrelu_conv_lrelu_conv_res_x3", 2 * di, 2 * di + 1, dil, one, false, true, src, dst)) {
+        for (int j = 0; j < kWinMulti; j++) src[j] = dst[j];
+        continue;
+      }
+      if (c.resblock_type == 2 && di + 1 < c.rb_n_dil) {
+        int dil2[kWinMulti];
+        for (int j = 0; j < kWinMulti; j++) dil2[j] = c.rb_dilations[j][di + 1];
+        if (add_pair(p + "rb012.c" + std::to_string(di) + std::to_string(di + 1) + "_lrelu_conv_res_pair_x3", di, di + 1, dil, dil2, true, false, src, dst)) {
+          for (int j = 0; j < kWinMulti; j++) src[j] = dst[j];
+          di++;
+          continue;
+        }
+      }
       if (c.resblock_type == 1) {
         const ConvW* wa[kWinMulti] = {&S.rb[0][2 * di], &S.rb[1][2 * di], &S.rb[2][2 * di]};
         const ConvW* wb[kWinMulti] = {&S.rb[0][2 * di + 1], &S.rb[1][2 * di + 1], &S.rb[2][2 * di + 1]};

@@ -476,3 +476,28 @@ def test_comm_single_rank_world(backend):
         c.close()
     with pytest.raises(ph.InvalidArgument):
         ph.Comm(backend, uid, 2, 2)
+
+
+# (type, C, T, K, dilations, batch): the fused pair kernel's geometry (C ∈ {32, 64}, T % 4 == 0) — T below / at / across the
+# 224-column block edge, odd pair counts (a pair + a single conv), every Piper kernel size and dilation set
+RB_PAIR_CASES = [
+    (2, 32, 224, 3, [1, 3], 1), (2, 32, 1000, 5, [2, 6], 1), (2, 32, 452, 7, [3, 12], 2), (2, 32, 8, 7, [1, 3], 1),
+    (2, 64, 228, 3, [1, 3], 1), (2, 64, 700, 7, [1, 3], 2), (2, 64, 448, 5, [1, 2, 3], 1),
+    (1, 64, 520, 11, [1, 3, 5], 1), (1, 64, 224, 3, [1, 3, 5], 2), (1, 32, 900, 7, [1, 3, 5], 1),
+]
+
+
+@pytest.mark.parametrize("case", RB_PAIR_CASES, ids=lambda c: f"rb{c[0]}_C{c[1]}_T{c[2]}_K{c[3]}_d{'-'.join(map(str, c[4]))}_n{c[5]}")
+def test_hifigan_resblock_fused_pairs(case, backend):
+    """rb_pair_kernel (two chained convs, intermediate in LDS) against the oracle's conv-by-conv ResBlock."""
+    type_, Cc, T, K, dils, N = case
+    sd = kd.case_seed("cfg", 500 + Cc + T + K)
+    nconv = len(dils) * (2 if type_ == 1 else 1)
+    x = kd.sym(sd, (N, Cc, T))
+    ws = [kd.weight(sd + 1 + i, (Cc, Cc, K), Cc * K) for i in range(nconv)]
+    bs = [kd.sym(sd + 40 + i, (Cc,), 0.1) for i in range(nconv)]
+    b = backend
+    out = b.hifiganResblockF32(type_, up(b, x), N, Cc, T, K, dils, [up(b, w) for w in ws], [up(b, v) for v in bs], 0.1)
+    got = b.downloadFloat32(out).reshape(N, Cc, T)
+    for n in range(N):
+        assert_close(got[n], orc.hifigan_resblock(type_, x[n:n + 1], K, dils, ws, bs)[0], OP_TOL, f"item {n} vs oracle")

@@ -8,6 +8,10 @@
 #include <cstdlib>
 #include <vector>
 
+#ifndef PH_PIPE_ABL
+#define PH_PIPE_ABL 0
+#endif
+
 #include "../../piper-swift_amd/csrc/conv_win.h"
 
 using namespace ph;
@@ -18,6 +22,7 @@ int main(int argc, char** argv) {
   if (argc > 3) sscanf(argv[3], "%d,%d,%d", &K[0], &K[1], &K[2]);
   if (argc > 4) sscanf(argv[4], "%d,%d,%d", &D[0], &D[1], &D[2]);
   const int res = argc > 5 ? atoi(argv[5]) : 1;
+  const bool win = argc > 6 && argv[6][0] == 'w';  // "win": time conv_win_kernel on the same problem instead
   piper_hip_ctx* ctx = nullptr;
   if (piper_hip_create(0, &ctx)) { fprintf(stderr, "%s\n", piper_hip_last_error()); return 1; }
   hipStream_t s;
@@ -28,7 +33,7 @@ int main(int argc, char** argv) {
     float *x, *y, *w, *wp, *b;
     hipMalloc(&x, (size_t)C * L * 4); hipMalloc(&y, (size_t)C * L * 4);
     hipMalloc(&w, (size_t)C * C * K[j] * 4); hipMalloc(&b, C * 4);
-    hipMalloc(&wp, packed_conv_pipe_floats(C, C, K[j]) * 4);
+    hipMalloc(&wp, (win ? packed_conv_win_floats(C, C, K[j]) : packed_conv_pipe_floats(C, C, K[j])) * 4);
     std::vector<float> h((size_t)C * L);
     for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.0f - 0.5f;
     hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -36,7 +41,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hw.size(); i++) hw[i] = ((float)((i * 40503u >> 4) & 0xfff) / 4096.0f - 0.5f) * 0.1f;
     hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     hipMemset(b, 0, C * 4);
-    pack_conv_weights_pipe(s, w, C, C, K[j], wp);
+    if (win) pack_conv_weights_win(s, w, C, C, K[j], wp);
+    else pack_conv_weights_pipe(s, w, C, C, K[j], wp);
     ConvWinArgs& c = a[j];
     c.x = x; c.w4 = wp; c.bias = b; c.res = res ? x : nullptr; c.y = y; c.pro_alpha = 0.1f;
     c.N = 1; c.Cin = C; c.Cout = C; c.K = K[j]; c.dil = D[j]; c.padL = (K[j] * D[j] - D[j]) / 2; c.Lin = L; c.Lout = L; c.y_len = L;
@@ -45,17 +51,18 @@ int main(int argc, char** argv) {
   hipStreamSynchronize(s);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 5; i++) launch_conv_pipe_multi(ctx, s, a, 3);
+  auto go = [&]() { return win ? launch_conv_win_multi(ctx, s, a, 3) : launch_conv_pipe_multi(ctx, s, a, 3); };
+  for (int i = 0; i < 5; i++) go();
   hipStreamSynchronize(s);
   const int reps = 50;
   hipEventRecord(e0, s);
-  for (int i = 0; i < reps; i++) launch_conv_pipe_multi(ctx, s, a, 3);
+  for (int i = 0; i < reps; i++) go();
   hipEventRecord(e1, s);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1000.0 / reps;
-  printf("ABL=%d C=%d L=%d K=%d,%d,%d d=%d,%d,%d res=%d: %.2f us  %.1f TFLOP/s  (%s)\n", PH_PIPE_ABL, C, L, K[0], K[1], K[2], D[0], D[1], D[2], res, us,
+  printf("%s ABL=%d C=%d L=%d K=%d,%d,%d d=%d,%d,%d res=%d: %.2f us  %.1f TFLOP/s  (%s)\n", win ? "win " : "pipe", PH_PIPE_ABL, C, L, K[0], K[1], K[2], D[0], D[1], D[2], res, us,
          flops / us * 1e-6, hipGetErrorString(hipGetLastError()));
   return 0;
 }
