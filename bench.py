@@ -407,7 +407,7 @@ def main():
                     n = sum(f["launches"] for f in fam)
                     return sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None
                 if args.factor == 8 and args.quality == "medium" and not bf16:
-                    traffic = per_launch(PROFILE_F32, ("conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel"))
+                    traffic = per_launch(PROFILE_F32, ("conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel", "rb_pair_kernel"))
                 elif args.factor == 8 and args.quality == "high" and bf16:
                     traffic = per_launch(PROFILE_BF16, ("conv_bf16_kernel",))
             except Exception:
@@ -415,7 +415,7 @@ def main():
             out["roofline"] = {
                 "kernel": ("conv_bf16_kernel (bf16-operand MFMA Conv1d/ConvTranspose1d of the generator, LDS-resident input window; all of its launches in one utterance)"
                            if bf16 else
-                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_stream_kernel for short rows + conv_win_kernel for the generator long rows; all of their launches in one utterance)"),
+                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_stream_kernel for short rows, conv_win_kernel / rb_pair_kernel for the generator long rows; all of their launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                 "traffic_note": f"HBM bytes per launch from profiles/{PROFILE_BF16 if bf16 else PROFILE_F32}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

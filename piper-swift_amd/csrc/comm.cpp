@@ -86,6 +86,7 @@ PH_EXPORT int piper_hip_comm_create(piper_hip_ctx* ctx, const void* id, int rank
   c->ctx = ctx;
   c->rank = rank;
   c->world = world;
+  (void)hipGetLastError();  // RCCL's init trips over a stale "last error" left by an earlier, already reported HIP failure
   ncclResult_t r = R.CommInitRank(&c->comm, world, uid, rank);  // collective: every rank of the world calls it
   if (r != ncclSuccess) {
     delete c;

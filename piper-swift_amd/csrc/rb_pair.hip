@@ -42,6 +42,14 @@ struct RbPairMulti {
   RbPairArgs c[kWinMulti];
 };
 
+// tools/probe/pairprobe -DPH_PAIR_TRACE: per wave and tile, s_memtime stamps at the phase boundaries (written to *ph_pair_trace)
+#ifdef PH_PAIR_TRACE
+__device__ unsigned long long* ph_pair_trace_buf;
+#define PH_STAMP(k) do { if (lane == 0 && round < 4 && ph_pair_trace_buf && blockIdx.x < 512) ph_pair_trace_buf[(((size_t)blockIdx.x * (MT * kWN) + wave) * 4 + round) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_STAMP(k) do { } while (0)
+#endif
+
 // LeakyReLU for 0 < α < 1 is max(v, αv). It is applied where a value is WRITTEN to LDS (staging, x1 epilogue), never in the
 // K-loops: on gfx950 a vector instruction does not overlap the matrix pipe of its SIMD — tools/probe/issueprobe, r2o: every
 // VALU op next to an MFMA costs ≈ 4 of the pipe's cycles (8 per MFMA: 150 → 107 TFLOP/s), scalar ops are free — so the loops
@@ -56,103 +64,130 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, float v, int vo
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
 }
 
+// Tile schedule of a launch: the (pair, batch item, column block) tiles in ONE list, heaviest pair first; block b of G walks
+// it in snake order (b, 2G−1−b, 2G+b, …) so that every block gets a similar mix of heavy and light tiles.
+struct PairSched {
+  int ntx[kWinMulti];  // column blocks per row, by position in `order`
+  int cnt[kWinMulti];  // tiles of that pair (ntx · batch)
+  int total, batch, order;
+};
+
 // MT row tiles (C = 32·MT); the block has MT·kWN waves: wave = (wm, wn), one row tile and kNTW column tiles each.
+// PERSISTENT: a block loops over its tiles; while it multiplies tile i, the window of tile i+1 is already on its way from
+// memory into registers (issued at the start of conv a, committed to LDS after conv b), and the weight ring of the next conv
+// is always started before the epilogue in front of it.
 template <int MT>
-__global__ __launch_bounds__(MT * kWN * 64) void rb_pair_kernel(const RbPairMulti multi, const int batch, const int order, const int Wx, const int W1,
+__global__ __launch_bounds__(MT * kWN * 64, 2) void rb_pair_kernel(const RbPairMulti multi, const PairSched sch, const int Wx, const int W1,
                                                                const unsigned inv_w4) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int BT = MT * kWN * 64;
-  const int jz = blockIdx.y / batch;
-  const RbPairArgs& p = multi.c[(order >> (4 * jz)) & 15];  // heaviest pair first: blocks are handed out in grid order
-  const int n = blockIdx.y - jz * batch;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wm = wave % MT, wn = wave / MT;
   const int r = lane & 31, h = lane >> 5;
-  const int C = 32 * MT, C2 = C >> 1;
-  const int pa = (p.Ka - 1) * p.dila / 2, pb = (p.Kb - 1) * p.dilb / 2;
-  const int halo = halo_of(pb), ncb = kColsA - 2 * halo;  // output columns per block: 224 or 160
-  const int c0 = blockIdx.x * ncb;                   // first output column of the block
-  if (c0 >= p.L) return;                             // the grid is sized for the launch's narrowest blocks
-  const int g0 = c0 - halo - pa;                     // input position of window column `shift`
-  const int ga = g0 & ~3;
-  const int shift = g0 - ga;
-  float* xs = lds;                                   // lrelu(x) window [C][Wx]; after conv a: raw x1 [C][W1] (ResBlock2's residual)
-  float* x1s = lds + C * Wx + 4;                     // lrelu(x1) [C][W1]   (+4: the staging dump slot)
-  const int Lv = p.len_ptr ? min(p.len_ptr[n] * p.len_mul, p.L) : p.L;
-  const float alpha = p.alpha;
-  const int ntb = min(max((ncb >> 5) - wn * kNTW, 0), kNTW);  // this wave's conv-b tiles (wave-uniform)
-
-  // ---- weight rings: conv a's first groups are requested before the window exists
-  const int Sa = p.Ka * C2, Spa = (Sa + kStepPad - 1) / kStepPad * kStepPad;
-  const int Sb = p.Kb * C2, Spb = (Sb + kStepPad - 1) / kStepPad * kStepPad;
-  const unsigned lane16 = (unsigned)lane * 16u;
-  float4 a[kRA];
-  const char* wa = (const char*)p.wa4 + (int64_t)wm * Spa * 256;
-  auto load_a = [&](int slot, int ahead) { a[slot] = *(const float4*)(wa + ahead * 1024 + lane16); };
-#pragma unroll
-  for (int d = 0; d < kRA - 1; d++) load_a(d, d);
-
-  // ---- biases of this lane's 16 rows, both convs, and the RAW x this wave adds as a residual (ResBlock2: to x1 on its
-  // conv-a tiles; ResBlock1: to y on its conv-b tiles) — requested now, used in the epilogues. Buffer loads: the lane part
-  // of the address is one register, the row part a scalar offset; columns left of the row (negative offset) read as 0.
-  float biasa[16], biasb[16], resx[kNTW][16];
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)n * C * p.L), 0, C * p.L * 4, 0x00020000);
+  constexpr int C = 32 * MT, C2 = C >> 1;
+  float* xs = lds;                 // lrelu(x) window [C][Wx]; after conv a: raw x1 [C][W1] (ResBlock2's residual)
+  float* x1s = lds + C * Wx + 4;   // lrelu(x1) [C][W1]   (+4: the staging dump slot)
+  // biases of every conv of the launch, [pair position z][a | b][C]: accumulators START at the bias (bias first, like
+  // CPUBackend.conv1d), read here with four ds_read_b128 per conv. (r2r trace: taking them through scalar loads inside the
+  // epilogues serialised every element behind an lgkmcnt(0) — 12 k + 9 k cycles per tile, 30 % of it.)
+  float* biasS = x1s + C * W1;
+  for (int i = threadIdx.x; i < kWinMulti * 2 * C; i += BT) {
+    const int z = i / (2 * C), rem = i - z * 2 * C;
+    const RbPairArgs& p = multi.c[(sch.order >> (4 * z)) & 15];
+    biasS[i] = rem < C ? p.ba[rem] : p.bb[rem - C];
+  }
   const int rowlane = wm * 32 + 4 * h;
-#pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const int row = rowlane + (q & 3) + 8 * (q >> 2);
-    biasa[q] = p.ba[row];
-    biasb[q] = p.bb[row];
-  }
-  {
-    const int gres0 = p.res_a ? c0 - halo : c0;  // position of column 0 of tile 0 of the residual's tile grid
-#pragma unroll
-    for (int j = 0; j < kNTW; j++) {
-      const int g = gres0 + (wn * kNTW + j) * 32 + r;
-      const int voff = (g >= 0 && g < p.L) ? (rowlane * p.L + g) * 4 : -4;  // −4: out of range ⇒ 0
-#pragma unroll
-      for (int q = 0; q < 16; q++) resx[j][q] = bload(rx, voff, ((q & 3) + 8 * (q >> 2)) * p.L * 4);
-    }
-  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int G = (int)gridDim.x, bid = (int)blockIdx.x;
 
-  // ---- stage lrelu(x): flat float4 index → (row, i4) by a multiply-high (exact for these sizes). ALL of a thread's loads
-  // are in flight at once (≤ kStageU·BT float4 per block, host-checked): one memory round trip
-  {
-    const float* xb = p.x + (int64_t)n * C * p.L;
-    const int W4 = Wx >> 2, total = C * W4, dump = C * Wx;
-    float4 t[kStageU];
-    int dst[kStageU], nv[kStageU];
+  struct Tile {  // wave-uniform description of one tile
+    const float *x, *wa4, *wb4;
+    float* y;
+    int bias_off;  // of conv a in biasS; conv b: + C
+    int Ka, dila, Kb, dilb, res_a, res_b_x, L, Lv, pa, pb, halo, c0, ga, shift, Sa, Spa, Sb, Spb, ntb;
+    float alpha;
+  };
+  auto tile_index = [&](int round) {
+    const int idx = round * G + ((round & 1) ? G - 1 - bid : bid);
+    return idx < sch.total ? idx : -1;
+  };
+  auto setup = [&](int idx) {
+    int z = 0, rem = idx;
+    if (rem >= sch.cnt[0]) { rem -= sch.cnt[0]; z = 1; }
+    if (z == 1 && rem >= sch.cnt[1]) { rem -= sch.cnt[1]; z = 2; }
+    const RbPairArgs& p = multi.c[(sch.order >> (4 * z)) & 15];
+    const int ntx = sch.ntx[z];
+    const int n = __builtin_amdgcn_readfirstlane(rem / ntx);  // the division runs on the vector ALU: tell the compiler the result is uniform
+    const int bx = rem - n * ntx;
+    Tile t;
+    t.x = p.x + (int64_t)n * C * p.L;
+    t.y = p.y + (int64_t)n * C * p.L;
+    t.wa4 = p.wa4; t.wb4 = p.wb4; t.bias_off = z * 2 * C;
+    t.Ka = p.Ka; t.dila = p.dila; t.Kb = p.Kb; t.dilb = p.dilb; t.res_a = p.res_a; t.res_b_x = p.res_b_x; t.L = p.L; t.alpha = p.alpha;
+    t.Lv = p.len_ptr ? min(p.len_ptr[n] * p.len_mul, p.L) : p.L;
+    t.pa = (p.Ka - 1) * p.dila / 2; t.pb = (p.Kb - 1) * p.dilb / 2;
+    t.halo = halo_of(t.pb);
+    const int ncb = kColsA - 2 * t.halo;            // output columns per tile: 224 or 160
+    t.c0 = bx * ncb;                                 // first output column
+    const int g0 = t.c0 - t.halo - t.pa;             // input position of window column `shift`
+    t.ga = g0 & ~3;
+    t.shift = g0 - t.ga;
+    t.Sa = p.Ka * C2; t.Spa = (t.Sa + kStepPad - 1) / kStepPad * kStepPad;
+    t.Sb = p.Kb * C2; t.Spb = (t.Sb + kStepPad - 1) / kStepPad * kStepPad;
+    t.ntb = min(max((ncb >> 5) - wn * kNTW, 0), kNTW);  // this wave's conv-b tiles
+    return t;
+  };
+
+  // ---- weight ring
+  float4 a[kRA];
+  const char* wa = nullptr;
+  auto load_a = [&](int slot, int ahead) { a[slot] = *(const float4*)(wa + ahead * 1024 + lane16); };
+  auto ring_start = [&](const float* w4, int Sp) {
+    wa = (const char*)w4 + (int64_t)wm * Sp * 256;
+#pragma unroll
+    for (int d = 0; d < kRA - 1; d++) load_a(d, d);
+  };
+
+  // ---- window staging in two halves: issue (global → registers, ALL of a thread's loads in flight), commit (→ LDS with
+  // LeakyReLU and the zero padding). flat float4 index → (row, i4) by a multiply-high (exact for these sizes)
+  float4 pre[kStageU];
+  const int W4 = Wx >> 2, total4 = C * W4;
+  auto stage_issue = [&](const Tile& t, const int tx) {
 #pragma unroll
     for (int u = 0; u < kStageU; u++) {
-      const int i = (int)threadIdx.x + u * BT;
-      const int ic = min(i, total - 1);
+      const int ic = min(tx + u * BT, total4 - 1);
+      const int row = (int)__umulhi((unsigned)ic, inv_w4);
+      const int pos = t.ga + 4 * (ic - row * W4);
+      pre[u] = *(const float4*)(t.x + (int64_t)row * t.L + ((pos >= 0 && pos < t.L) ? pos : 0));
+    }
+  };
+  auto stage_commit = [&](const Tile& t, const int tx) {
+#pragma unroll
+    for (int u = 0; u < kStageU; u++) {
+      const int i = tx + u * BT;
+      const int ic = min(i, total4 - 1);
       const int row = (int)__umulhi((unsigned)ic, inv_w4);
       const int i4 = ic - row * W4;
-      const int pos = ga + 4 * i4;
-      const bool inb = pos >= 0 && pos < p.L;
-      t[u] = *(const float4*)(xb + (int64_t)row * p.L + (inb ? pos : 0));
-      nv[u] = inb ? Lv - pos : 0;
-      dst[u] = i < total ? row * Wx + 4 * i4 : dump;
+      const int pos = t.ga + 4 * i4;
+      const int nv = (pos >= 0 && pos < t.L) ? t.Lv - pos : 0;
+      float4 v = pre[u];
+      v.x = nv > 0 ? lrelu_max(v.x, t.alpha) : 0.0f; v.y = nv > 1 ? lrelu_max(v.y, t.alpha) : 0.0f;
+      v.z = nv > 2 ? lrelu_max(v.z, t.alpha) : 0.0f; v.w = nv > 3 ? lrelu_max(v.w, t.alpha) : 0.0f;
+      *(float4*)(xs + (i < total4 ? row * Wx + 4 * i4 : C * Wx)) = v;
     }
-#pragma unroll
-    for (int u = 0; u < kStageU; u++) {
-      float4 v = t[u];
-      v.x = nv[u] > 0 ? lrelu_max(v.x, alpha) : 0.0f; v.y = nv[u] > 1 ? lrelu_max(v.y, alpha) : 0.0f;
-      v.z = nv[u] > 2 ? lrelu_max(v.z, alpha) : 0.0f; v.w = nv[u] > 3 ? lrelu_max(v.w, alpha) : 0.0f;
-      *(float4*)(xs + dst[u]) = v;
-    }
-  }
-  __syncthreads();
+  };
 
   // ---- one conv over this wave's column tiles: B straight from an LDS image [C][Wrow], A through the ring
   f32x16 acc[kNTW];
-  auto run_conv = [&](auto nt_tag, const float* img, const int Wrow, const int S, const int Sp, const int dil, const int col0) {
+  auto run_conv = [&](auto nt_tag, const float* img, const int Wrow, const int S, const int Sp, const int dil, const int col0, const int bias_off) {
     constexpr int NT = decltype(nt_tag)::value;
 #pragma unroll
-    for (int j = 0; j < kNTW; j++)
+    for (int g4 = 0; g4 < 4; g4++) {  // register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h
+      const float4 bv = *(const float4*)(biasS + bias_off + rowlane + 8 * g4);
 #pragma unroll
-      for (int q = 0; q < 16; q++) acc[j][q] = 0.0f;
+      for (int j = 0; j < kNTW; j++) { acc[j][4 * g4] = bv.x; acc[j][4 * g4 + 1] = bv.y; acc[j][4 * g4 + 2] = bv.z; acc[j][4 * g4 + 3] = bv.w; }
+    }
     const int lbase = h * Wrow + col0 + r;
     int sidx = 0, c_n = 0, left = S - 1;  // the index stops at the last real step (padded steps carry zero weights)
     const int wrap_delta = dil - 2 * Wrow * (C2 - 1);
@@ -183,70 +218,126 @@ __global__ __launch_bounds__(MT * kWN * 64) void rb_pair_kernel(const RbPairMult
         for (int j = 0; j < NT; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], b[u & 1][j][e], acc[j], 0, 0, 0);
     };
     read_b4(0);
-    const int G = Sp >> 2, full = G / kRA;
-    for (int g = 0; g < full; g++) {
+    const int Gr = Sp >> 2, full = Gr / kRA;
+    // The first ring turn is straight-line code: loads issued just before this conv (the next tile's window, the residual)
+    // are younger than the ring's first groups, and only straight-line code lets the compiler count them precisely — inside
+    // the loop every wait is vmcnt(7), which on the first turn would wait for those fresh loads at once.
+    if (full > 0) {
 #pragma unroll
       for (int u = 0; u < kRA; u++) group(u);
       wa += kRA * 1024;
     }
-    const int rem = G - full * kRA;
+    for (int g = 1; g < full; g++) {
+#pragma unroll
+      for (int u = 0; u < kRA; u++) group(u);
+      wa += kRA * 1024;
+    }
+    const int rem = Gr - full * kRA;
 #pragma unroll
     for (int u = 0; u < kRA - 1; u++)
       if (u < rem) group(u);
   };
 
-  // ======== conv a: x1 columns [c0 − halo, c0 − halo + 256) = tiles wn·2, wn·2 + 1 of the block's 8
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the ring's first groups have landed long ago (clean state for the loop)
-  run_conv(std::integral_constant<int, kNTW>{}, xs, Wx, Sa, Spa, p.dila, shift + wn * kNTW * 32);
-
-  // conv b's ring starts now: its round trip hides behind the x1 epilogue and the barriers
-  wa = (const char*)p.wb4 + (int64_t)wm * Spb * 256;
-#pragma unroll
-  for (int d = 0; d < kRA - 1; d++) load_a(d, d);
-  __syncthreads();  // every wave is done reading the x window: its memory now takes the raw x1
-
-  {  // x1 = [x +] acc + bias, zero outside [0, len): lrelu(x1) → x1s (conv b's operand), raw x1 → xs region (ResBlock2's
-     // residual). register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r
-#pragma unroll
-    for (int j = 0; j < kNTW; j++) {
-      const int colw = (wn * kNTW + j) * 32 + r;      // x1 column
-      const int g = c0 - halo + colw;                  // its position in the row
-      const bool in = g >= 0 && g < Lv;
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int o = (rowlane + (q & 3) + 8 * (q >> 2)) * W1 + colw;
-        float v = acc[j][q] + biasa[q];
-        if (p.res_a) v += resx[j][q];
-        v = in ? v : 0.0f;
-        x1s[o] = lrelu_max(v, alpha);
-        if (!p.res_b_x) xs[o] = v;
-      }
-    }
-  }
+  // ================= cold start: first tile's ring and window
+  Tile cur = setup(tile_index(0));  // the grid never exceeds the tile count
+  ring_start(cur.wa4, cur.Spa);
+  stage_issue(cur, (int)threadIdx.x);
+  stage_commit(cur, (int)threadIdx.x);
   __syncthreads();
 
-  // ======== conv b: the block's ncb / 32 output tiles, two per wave column (the last ones get one or none)
-  if (ntb == 0) return;
-  const int col0b = halo - pb + wn * kNTW * 32;
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  if (ntb == 2) run_conv(std::integral_constant<int, 2>{}, x1s, W1, Sb, Spb, p.dilb, col0b);
-  else run_conv(std::integral_constant<int, 1>{}, x1s, W1, Sb, Spb, p.dilb, col0b);
+  for (int round = 0;; round++) {
+    const int nidx = tile_index(round + 1);
+    const bool has_next = nidx >= 0;          // block-uniform
+    const Tile nxt = has_next ? setup(nidx) : cur;
+    // Lane-dependent offsets (staging rows, epilogue addresses) are the same for every tile; left alone the compiler hoists
+    // all ≈ 90 of them out of the tile loop and the kernel no longer fits 256 registers. Opaque copies of the lane ids per
+    // tile keep them where they are used.
+    int tx = (int)threadIdx.x, rl = rowlane, rr = r;
+    asm volatile("" : "+v"(tx), "+v"(rl), "+v"(rr));
+    // the RAW x this wave adds as a residual (ResBlock2: to x1 on its conv-a tiles; ResBlock1: to y on its conv-b tiles) is
+    // requested right after the conv in front of the epilogue that uses it. Buffer loads: lane part of the address in one
+    // register, row part a scalar offset; out of range ⇒ 0.
+    float resx[kNTW][16];
+    auto load_res = [&](int gres0) {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)cur.x, 0, C * cur.L * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < kNTW; j++) {
+        const int g = gres0 + (wn * kNTW + j) * 32 + rr;
+        const int voff = (g >= 0 && g < cur.L) ? (rl * cur.L + g) * 4 : -4;
+#pragma unroll
+        for (int q = 0; q < 16; q++) resx[j][q] = bload(rx, voff, ((q & 3) + 8 * (q >> 2)) * cur.L * 4);
+      }
+    };
 
-  {  // y = acc + bias + (x | x1) → global; 2 rows × 32 consecutive columns per store instruction
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (int64_t)n * C * p.L), 0, C * p.L * 4, 0x00020000);
+    PH_STAMP(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): ring a landed (issued before the previous epilogue): clean state
+    PH_STAMP(1);
+    if (has_next) stage_issue(nxt, tx);  // next tile's window: in flight during conv a, held in registers through conv b
+
+    // ======== conv a: x1 columns [c0 − halo, c0 − halo + 256) = tiles wn·2, wn·2 + 1 of the tile's 8
+    run_conv(std::integral_constant<int, kNTW>{}, xs, Wx, cur.Sa, cur.Spa, cur.dila, cur.shift + wn * kNTW * 32, cur.bias_off);
+    PH_STAMP(2);
+    ring_start(cur.wb4, cur.Spb);  // conv b's ring: its round trip hides behind the x1 epilogue and the barriers
+    if (cur.res_a) load_res(cur.c0 - cur.halo);
+    __syncthreads();               // every wave is done reading the x window: its memory now takes the raw x1
+    PH_STAMP(3);
+
+    {  // x1 = [x +] acc (bias inside), zero outside [0, len): lrelu(x1) → x1s (conv b's operand), raw x1 → xs region (ResBlock2's
+       // residual). register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r
 #pragma unroll
-    for (int j = 0; j < kNTW; j++) {
-      if (j >= ntb) break;
-      const int colo = (wn * kNTW + j) * 32 + r;       // output column within the block
-      const int g = c0 + colo;
-      const int voff = g < p.L ? (rowlane * p.L + g) * 4 : -4;  // −4: out of range ⇒ the store is dropped
+      for (int j = 0; j < kNTW; j++) {
+        const int colw = (wn * kNTW + j) * 32 + rr;       // x1 column
+        const int g = cur.c0 - cur.halo + colw;           // its position in the row
+        const bool in = g >= 0 && g < cur.Lv;
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        float v = acc[j][q] + biasb[q];
-        v += p.res_b_x ? resx[j][q] : xs[(rowlane + (q & 3) + 8 * (q >> 2)) * W1 + halo + colo];
-        bstore(ry, v, voff, ((q & 3) + 8 * (q >> 2)) * p.L * 4);
+        for (int q = 0; q < 16; q++) {
+          const int rq = (q & 3) + 8 * (q >> 2);
+          const int o = (rl + rq) * W1 + colw;
+          float v = acc[j][q];
+          if (cur.res_a) v += resx[j][q];
+          v = in ? v : 0.0f;
+          x1s[o] = lrelu_max(v, cur.alpha);
+          if (!cur.res_b_x) xs[o] = v;
+        }
       }
     }
+    __syncthreads();
+
+    PH_STAMP(4);
+    // ======== conv b: the tile's output tiles, two per wave column (the last ones get one or none)
+    if (cur.ntb > 0) {
+      const int col0b = cur.halo - cur.pb + wn * kNTW * 32;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      if (cur.ntb == 2) run_conv(std::integral_constant<int, 2>{}, x1s, W1, cur.Sb, cur.Spb, cur.dilb, col0b, cur.bias_off + C);
+      else run_conv(std::integral_constant<int, 1>{}, x1s, W1, cur.Sb, cur.Spb, cur.dilb, col0b, cur.bias_off + C);
+    }
+    PH_STAMP(5);
+    if (has_next) ring_start(nxt.wa4, nxt.Spa);  // next tile's conv a ring: lands during the epilogue and the barriers
+    if (cur.res_b_x && cur.ntb > 0) load_res(cur.c0);
+    if (cur.ntb > 0) {  // y = acc (bias inside) + (x | x1) → global; 2 rows × 32 consecutive columns per store instruction
+      const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)cur.y, 0, C * cur.L * 4, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < kNTW; j++) {
+        if (j >= cur.ntb) break;
+        const int colo = (wn * kNTW + j) * 32 + rr;        // output column within the tile
+        const int g = cur.c0 + colo;
+        const int voff = g < cur.L ? (rl * cur.L + g) * 4 : -4;  // −4: out of range ⇒ the store is dropped
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int rq = (q & 3) + 8 * (q >> 2);
+          float v = acc[j][q];
+          v += cur.res_b_x ? resx[j][q] : xs[(rl + rq) * W1 + cur.halo + colo];
+          bstore(ry, v, voff, rq * cur.L * 4);
+        }
+      }
+    }
+    PH_STAMP(6);
+    if (!has_next) break;
+    __syncthreads();      // every wave is done with both LDS images
+    stage_commit(nxt, tx);
+    __syncthreads();
+    PH_STAMP(7);
+    cur = nxt;
   }
 }
 
@@ -269,22 +360,28 @@ PairGeom pair_geom(int C, int pa_max, int pb_max) {
     g.Wx = pad(kColsA + 2 * pa_max + 3, pass == 0);
     g.W1 = pad(kColsA, pass == 0);
     (void)pb_max;
-    g.lds = ((size_t)C * g.Wx + 4 + (size_t)C * g.W1) * sizeof(float);
+    g.lds = ((size_t)C * g.Wx + 4 + (size_t)C * g.W1 + (size_t)kWinMulti * 2 * C) * sizeof(float);
     if (g.lds <= 160 * 1024 && (C * g.Wx) / 4 <= kStageU * (C / 32) * kWN * 64) break;
   }
   return g;
 }
 
 template <int MT>
-void launch_pair_inst(hipStream_t s, const RbPairMulti& m, int batch, int order, const PairGeom& g, dim3 grid) {
+void launch_pair_inst(piper_hip_ctx* ctx, hipStream_t s, const RbPairMulti& m, const PairSched& sch, const PairGeom& g) {
   static bool raised[kMaxDevices] = {};
   if (g.lds > 64 * 1024 && lds_optin_needed(raised))
     (void)hipFuncSetAttribute((const void*)rb_pair_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const unsigned inv = (unsigned)(0x100000000ull / (unsigned)(g.Wx >> 2)) + 1u;
-  hipLaunchKernelGGL((rb_pair_kernel<MT>), grid, dim3(MT * kWN * 64), g.lds, s, m, batch, order, g.Wx, g.W1, inv);
+  const int per_cu = std::max(1, std::min(2, (int)((size_t)160 * 1024 / g.lds)));  // resident blocks per CU (LDS; ≤ 256 VGPRs ⇒ ≤ 2 waves/SIMD)
+  const int grid = std::min(sch.total, per_cu * ctx->num_cus);
+  hipLaunchKernelGGL((rb_pair_kernel<MT>), dim3(grid), dim3(MT * kWN * 64), g.lds, s, m, sch, g.Wx, g.W1, inv);
 }
 
 }  // namespace
+
+#ifdef PH_PAIR_TRACE
+void rb_pair_set_trace(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ph_pair_trace_buf), &buf, sizeof buf); }
+#endif
 
 bool rb_pair_eligible(int C, int Ka, int dila, int Kb, int dilb, int L) {
   if (C != 32 && C != 64) return false;
@@ -316,13 +413,20 @@ int launch_rb_pair_multi(piper_hip_ctx* ctx, hipStream_t s, const RbPairArgs* pa
   if (g.lds > 160 * 1024 || (a.C * g.Wx) / 4 > kStageU * (a.C / 32) * kWN * 64)
     PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "rb_pair: window of %zu bytes (row %d) exceeds LDS / the staging registers", g.lds, g.Wx);
   std::sort(idx, idx + count, [&](int l, int r2) { return pairs[l].Ka + pairs[l].Kb > pairs[r2].Ka + pairs[r2].Kb; });
-  int order = 0;
-  for (int i = 0; i < count; i++) order |= idx[i] << (4 * i);
+  PairSched sch = {};
+  sch.batch = a.N;
+  for (int i = 0; i < count; i++) {
+    const RbPairArgs& b = pairs[idx[i]];
+    sch.order |= idx[i] << (4 * i);
+    sch.ntx[i] = (int)ceil_div(a.L, kColsA - 2 * halo_of((b.Kb - 1) * b.dilb / 2));
+    sch.cnt[i] = sch.ntx[i] * a.N;
+    sch.total += sch.cnt[i];
+  }
+  for (int i = count; i < kWinMulti; i++) { sch.ntx[i] = 1; sch.cnt[i] = 0; }
   RbPairMulti m;
   for (int i = 0; i < kWinMulti; i++) m.c[i] = pairs[i < count ? i : 0];
-  const dim3 grid((unsigned)ceil_div(a.L, kColsA - 2 * halo_of(pb_max)), (unsigned)(a.N * count));
-  if (a.C == 32) launch_pair_inst<1>(s, m, a.N, order, g, grid);
-  else launch_pair_inst<2>(s, m, a.N, order, g, grid);
+  if (a.C == 32) launch_pair_inst<1>(ctx, s, m, sch, g);
+  else launch_pair_inst<2>(ctx, s, m, sch, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rb_pair launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;

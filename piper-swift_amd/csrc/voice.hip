@@ -1239,7 +1239,10 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   // Advancing the three ResBlocks in one launch pays while a single conv cannot fill the chip (short utterances, small
   // batches); with many tiles per conv (NB·F large) the per-conv schedule with the mean fused into its producer is faster
   // (measured at 8 × factor 8: 2 650 vs 2 840 utterances/s).
-  if (use_win && !no_merge && !parallel_rb && (int64_t)NB * F <= 1536) {
+  // r2t: with two chained convs per launch (rb_pair.hip) the merged schedule is also the faster one for long rows;
+  // PIPER_HIP_MERGED_MAX_F restores a frames × batch limit for A/B runs.
+  static const int64_t merged_max = [] { const char* e = getenv("PIPER_HIP_MERGED_MAX_F"); return e ? (int64_t)atoll(e) : (int64_t)1 << 40; }();
+  if (use_win && !no_merge && !parallel_rb && (int64_t)NB * F <= merged_max) {
     const size_t mark = s.steps.size();
     const int rcm = build_generator_merged(v, s, ar, dec0, F, NB);
     if (rcm != PIPER_HIP_ERR_UNSUPPORTED) return rcm;

@@ -4,6 +4,7 @@
 // usage: pairprobe C L K0,K1,K2 da0,da1,da2 db0,db1,db2 [check]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,9 @@
 #include "../../piper-swift_amd/csrc/conv_win.h"
 
 using namespace ph;
+#ifdef PH_PAIR_TRACE
+namespace ph { void rb_pair_set_trace(unsigned long long* buf); }
+#endif
 
 static void cpu_conv(const std::vector<float>& x, const std::vector<float>& w, const std::vector<float>& b, int C, int L, int K, int d, float alpha,
                      const float* res, std::vector<float>& y) {
@@ -85,6 +89,39 @@ int main(int argc, char** argv) {
       printf("  pair %d (K=%d da=%d db=%d): max|err| = %.3e at row %zu col %zu\n", j, K[j], DA[j], DB[j], err, at / L, at % L);
     }
   }
+#ifdef PH_PAIR_TRACE
+  {
+    const size_t nst = (size_t)512 * 8 * 4 * 8;
+    unsigned long long* tb;
+    (void)hipMalloc(&tb, nst * 8);
+    (void)hipMemset(tb, 0, nst * 8);
+    rb_pair_set_trace(tb);
+    launch_rb_pair_multi(ctx, s, a, 3);
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> h(nst);
+    (void)hipMemcpy(h.data(), tb, nst * 8, hipMemcpyDeviceToHost);
+    const char* names[8] = {"top", "ring-a wait", "conv a", "ring b + res + barrier", "epilogue a + barrier", "conv b", "ring a' + epilogue b", "barrier + commit + barrier"};
+    const int waves = C / 8;  // per block
+    for (int round = 0; round < 4; round++) {
+      double sum[8] = {0}, tile = 0;
+      int cnt = 0;
+      unsigned long long kmin = ~0ull, kmax = 0;
+      for (int b = 0; b < 512; b++)
+        for (int w = 0; w < waves; w++) {
+          const unsigned long long* t = &h[(((size_t)b * waves + w) * 4 + round) * 8];
+          if (!t[0] || !t[6]) continue;
+          for (int k = 1; k < 7; k++) sum[k] += (double)(t[k] - t[k - 1]);
+          if (t[7]) sum[7] += (double)(t[7] - t[6]);
+          tile += (double)(t[6] - t[0]);
+          kmin = std::min(kmin, t[0]); kmax = std::max(kmax, t[6]);
+          cnt++;
+        }
+      if (!cnt) continue;
+      printf("  round %d (%d waves): tile %.0f ticks; span of the round %.0f ticks (s_memtime: shader cycles)\n", round, cnt, tile / cnt, (double)(kmax - kmin));
+      for (int k = 1; k < 8; k++) printf("    %-28s %8.1f ticks\n", names[k], sum[k] / cnt);
+    }
+  }
+#endif
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 5; i++) launch_rb_pair_multi(ctx, s, a, 3);
