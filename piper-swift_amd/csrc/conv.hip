@@ -105,10 +105,13 @@ __global__ __launch_bounds__(kBlock) void conv_direct_kernel(const ConvArgs p) {
 // is read from memory exactly once and all of a thread's loads are independent (issued back to back).
 constexpr int kSmallCoutMax = 4, kSmallCK = 32, kSmallBT = 256;
 template <int PRO, int COUT>
-__global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArgs p, const int vec4) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int halo = (p.K - 1) * (p.dil < 0 ? -p.dil : p.dil);
-  const int W = kSmallBT + halo;
+  // vec4 (rows 16-byte aligned, forward channels and taps): the window starts at the aligned position below `lo` and is staged
+  // as float4s — 8 channels × (1 or 3 sources) per thread, ALL in flight (one memory round trip per 32-channel chunk instead
+  // of twelve dependent batches of dword loads: conv_post 28 → r2 µs at factor 8)
+  const int W = vec4 ? ((kSmallBT + halo + 3 + 3) & ~3) : kSmallBT + halo;
   float* xs = sm;                  // [kSmallCK][W]
   float* ws = sm + kSmallCK * W;   // [Cout][kSmallCK][K]
   const int n = blockIdx.y, t0 = blockIdx.x * kSmallBT, tid = threadIdx.x;
@@ -126,6 +129,35 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
     __syncthreads();
     // channel rows × window columns: column = tid (+ 256 per extra pass), so there is no per-element division and the
     // 8-way unrolled channel loop keeps 8 independent loads per thread in flight
+    if (vec4) {
+      const int la = lo & ~3;              // aligned position of window column 0
+      const int W4 = W >> 2;
+      const int cg = tid >> 6, pt = tid & 63;  // 4 channel groups of 8 × 64 float4 columns
+      for (int i4 = pt; i4 < W4; i4 += 64) {
+        const int pos = la + 4 * i4;       // multiple of 4: a float4 is inside or outside [0, Lin) as a whole
+        const bool inb = pos >= 0 && pos < p.Lin;
+        const int nvalid = inb ? Lv - pos : 0;
+        float4 t[8], t2[PRO == PRO_AVG3_LRELU ? 8 : 1], t3[PRO == PRO_AVG3_LRELU ? 8 : 1];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int c = min(cg * 8 + q, ck - 1);
+          const int64_t off = (int64_t)(c0 + c) * p.Lin + (inb ? pos : 0);
+          t[q] = *(const float4*)(xb + off);
+          if constexpr (PRO == PRO_AVG3_LRELU) { t2[q] = *(const float4*)(x2b + off); t3[q] = *(const float4*)(x3b + off); }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          float4 v = t[q];
+          if constexpr (PRO == PRO_AVG3_LRELU) {
+            v.x = ((v.x + t2[q].x) + t3[q].x) / 3.0f; v.y = ((v.y + t2[q].y) + t3[q].y) / 3.0f;
+            v.z = ((v.z + t2[q].z) + t3[q].z) / 3.0f; v.w = ((v.w + t2[q].w) + t3[q].w) / 3.0f;
+          }
+          if constexpr (PRO != PRO_NONE) { v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha); }
+          v.x = nvalid > 0 ? v.x : 0.0f; v.y = nvalid > 1 ? v.y : 0.0f; v.z = nvalid > 2 ? v.z : 0.0f; v.w = nvalid > 3 ? v.w : 0.0f;
+          if (cg * 8 + q < ck) *(float4*)(xs + (cg * 8 + q) * W + 4 * i4) = v;
+        }
+      }
+    } else
     for (int cb = 0; cb < W; cb += kSmallBT) {
       const int col = cb + tid;
       const int pos = lo + col;
@@ -148,7 +180,7 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
       ws[(co * kSmallCK + c) * p.K + k] = p.w[((int64_t)co * p.Cin + c0 + c) * p.K + k];
     }
     __syncthreads();
-    const int colbase = tid - p.padL - (lo - t0);  // window column of tap 0 for this thread
+    const int colbase = tid - p.padL - (lo - t0) + (vec4 ? (lo & 3) : 0);  // window column of tap 0 for this thread
     for (int c = 0; c < ck; c++) {
       const float* xr = xs + c * W + colbase;
 #pragma unroll 8
@@ -163,6 +195,89 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
   if (xo < p.Lout) {
 #pragma unroll
     for (int co = 0; co < COUT; co++) store_elem(p, n, co, xo, acc[co]);
+  }
+}
+
+// conv_post at its real size (Cout 1, kernel 7, 'same' padding, rows of 86 016 … 688 128 steps, input = MRF mean of three
+// tensors): the one-output-per-thread kernel above is bound by its LDS reads (7 window + 7 weight reads per channel and
+// output). Here a thread owns FOUR consecutive outputs: per channel 4 aligned ds_read_b128 give the 4 + K − 1 window values,
+// 2 broadcast ds_read_b128 the taps — 6 LDS reads per 28 FMAs instead of 56 — and the window is staged 8 channels at a time as
+// float4s with the NEXT chunk's loads (≤ 27 per thread) in flight under the current chunk's arithmetic.
+constexpr int kWideBT = 256, kWideOut = 4 * kWideBT, kWideCK = 8, kWideW = kWideOut + 16, kWideK = 7, kWidePad = 3;
+template <int PRO>
+__global__ __launch_bounds__(kWideBT) void conv_cout1_wide_kernel(const ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float xs[kWideCK * kWideW];
+  __shared__ __attribute__((aligned(16))) float ws[256 * 8];  // [Cin ≤ 256][8]: 7 taps + a zero
+  constexpr bool AVG = PRO == PRO_AVG3_LRELU;
+  const int n = blockIdx.y, t0 = blockIdx.x * kWideOut, tid = threadIdx.x;
+  const int Lv = true_len(p, n);
+  if (p.len_ptr && t0 >= Lv) return;  // block-uniform: every output lies past the true length
+  const int la = t0 - 4;               // aligned position of window column 0 (t0 − pad = la + 1)
+  const float* xb = p.x + (int64_t)n * p.x_batch_stride;
+  const float* x2b = AVG ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
+  const float* x3b = AVG ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+  for (int i = tid; i < p.Cin * 8; i += kWideBT) ws[i] = (i & 7) < kWideK ? p.w[(i >> 3) * kWideK + (i & 7)] : 0.0f;
+  constexpr int kRows4 = kWideW / 4;   // 260 float4 per row: 256 by the thread's own column, 4 more by threads 0..31 (row = tid >> 2)
+  float4 t[kWideCK + 1], t2[AVG ? kWideCK + 1 : 1], t3[AVG ? kWideCK + 1 : 1];
+  auto slot = [&](int q, int& row, int& i4) {  // staging slot q of this thread → (row, float4 column); row ≥ kWideCK: none
+    row = q < kWideCK ? q : (tid < 32 ? (tid >> 2) : kWideCK);
+    i4 = q < kWideCK ? tid : 256 + (tid & 3);
+  };
+  auto issue = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q <= kWideCK; q++) {
+      int row, i4;
+      slot(q, row, i4);
+      const int pos = la + 4 * i4;
+      const int c = min(c0 + min(row, kWideCK - 1), p.Cin - 1);
+      const int64_t off = (int64_t)c * p.Lin + ((pos >= 0 && pos < p.Lin) ? pos : 0);
+      t[q] = *(const float4*)(xb + off);
+      if constexpr (AVG) { t2[q] = *(const float4*)(x2b + off); t3[q] = *(const float4*)(x3b + off); }
+    }
+  };
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q <= kWideCK; q++) {
+      int row, i4;
+      slot(q, row, i4);
+      const int pos = la + 4 * i4;
+      const int nvalid = (pos >= 0 && pos < p.Lin && c0 + row < p.Cin) ? Lv - pos : 0;
+      float4 v = t[q];
+      if constexpr (AVG) {  // ((x + x2) + x3) / 3: the association of the graph's Add, Add, Div
+        v.x = ((v.x + t2[q].x) + t3[q].x) / 3.0f; v.y = ((v.y + t2[q].y) + t3[q].y) / 3.0f;
+        v.z = ((v.z + t2[q].z) + t3[q].z) / 3.0f; v.w = ((v.w + t2[q].w) + t3[q].w) / 3.0f;
+      }
+      if constexpr (PRO != PRO_NONE) { v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha); }
+      v.x = nvalid > 0 ? v.x : 0.0f; v.y = nvalid > 1 ? v.y : 0.0f; v.z = nvalid > 2 ? v.z : 0.0f; v.w = nvalid > 3 ? v.w : 0.0f;
+      if (row < kWideCK) *(float4*)(xs + row * kWideW + 4 * i4) = v;
+    }
+  };
+  float acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; o++) acc[o] = p.bias ? p.bias[0] : 0.0f;  // bias first (CPUBackend.conv1d)
+  issue(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += kWideCK) {
+    __syncthreads();                     // the previous chunk's readers are done (first pass: ws is complete)
+    commit(c0);
+    __syncthreads();
+    if (c0 + kWideCK < p.Cin) issue(c0 + kWideCK);
+    const int ck = min(kWideCK, p.Cin - c0);
+    for (int c = 0; c < ck; c++) {       // ci-major, then k: the reference's order
+      const float4* xr = (const float4*)(xs + c * kWideW + 4 * tid);
+      const float4 v0 = xr[0], v1 = xr[1], v2 = xr[2], v3 = xr[3];
+      const float4 w0 = *(const float4*)(ws + (c0 + c) * 8), w1 = *(const float4*)(ws + (c0 + c) * 8 + 4);
+      const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int k = 0; k < kWideK; k++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) acc[o] += v[1 + o + k] * w[k];  // output 4·tid + o, tap k: window column 4·tid + 1 + o + k
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    const int xo = t0 + 4 * tid + o;
+    if (xo < p.Lout) store_elem(p, n, 0, xo, acc[o]);
   }
 }
 
@@ -356,15 +471,35 @@ int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
   if (a.epilogue == EPI_WN_RES_SKIP || a.epilogue == EPI_WN_SKIP_LAST || a.epilogue == EPI_CONVT || a.gate)
     PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "direct conv does not implement epilogue %d", a.epilogue);
   const int halo = (a.K - 1) * (a.dil < 0 ? -a.dil : a.dil);
+  static const bool no_wide = getenv("PIPER_HIP_NO_WIDE_POST") != nullptr;
+  if (!no_wide && a.Cout == 1 && a.K == kWideK && a.dil == 1 && a.padL == kWidePad && a.stride == 1 && a.groups == 1 && a.Lin == a.Lout && a.Cin <= 256 &&
+      a.N <= 65535 && a.in_ch_sign > 0 && a.in_ch_base == 0 && a.out_ch_sign > 0 && a.out_ch_base == 0 && (a.Lin & 3) == 0 && (a.x_batch_stride & 3) == 0 &&
+      ((uintptr_t)a.x & 15) == 0 && a.Lin >= 64 * kWideOut &&
+      (a.prologue != PRO_AVG3_LRELU || ((((uintptr_t)a.x2 | (uintptr_t)a.x3) & 15) == 0)) &&
+      (a.epilogue == EPI_STORE || a.epilogue == EPI_TANH) && !a.res && !a.gate) {
+    const dim3 g((unsigned)ceil_div(a.Lout, kWideOut), (unsigned)a.N);
+    switch (a.prologue) {
+      case PRO_NONE: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_NONE>, g, dim3(kWideBT), 0, s, a); break;
+      case PRO_LRELU: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_LRELU>, g, dim3(kWideBT), 0, s, a); break;
+      default: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_AVG3_LRELU>, g, dim3(kWideBT), 0, s, a); break;
+    }
+    hipError_t e3 = hipGetLastError();
+    if (e3 != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_cout1_wide launch failed: %s", hipGetErrorString(e3));
+    return PIPER_HIP_OK;
+  }
   if (a.Cout <= kSmallCoutMax && a.stride == 1 && a.groups == 1 && a.N <= 65535 && halo <= 1024 && a.K <= 64) {
     const dim3 g((unsigned)ceil_div(a.Lout, kSmallBT), (unsigned)a.N);
-    const size_t lds = ((size_t)kSmallCK * (kSmallBT + halo) + (size_t)a.Cout * kSmallCK * a.K) * sizeof(float);
+    // float4 staging: every row 16-byte aligned, channels and taps ascending
+    const int vec4 = (a.dil > 0 && a.in_ch_sign > 0 && a.in_ch_base == 0 && (a.Lin & 3) == 0 && (a.x_batch_stride & 3) == 0 && ((uintptr_t)a.x & 15) == 0 &&
+                      (a.prologue != PRO_AVG3_LRELU || ((((uintptr_t)a.x2 | (uintptr_t)a.x3) & 15) == 0))) ? 1 : 0;
+    const int Wl = vec4 ? ((kSmallBT + halo + 6) & ~3) : kSmallBT + halo;
+    const size_t lds = ((size_t)kSmallCK * Wl + (size_t)a.Cout * kSmallCK * a.K) * sizeof(float);
 #define PH_SMALL(PROV)                                                                                                   \
   switch (a.Cout) {                                                                                                     \
-    case 1: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 1>), g, dim3(kSmallBT), lds, s, a); break;                 \
-    case 2: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 2>), g, dim3(kSmallBT), lds, s, a); break;                 \
-    case 3: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 3>), g, dim3(kSmallBT), lds, s, a); break;                 \
-    default: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 4>), g, dim3(kSmallBT), lds, s, a); break;                \
+    case 1: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 1>), g, dim3(kSmallBT), lds, s, a, vec4); break;                 \
+    case 2: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 2>), g, dim3(kSmallBT), lds, s, a, vec4); break;                 \
+    case 3: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 3>), g, dim3(kSmallBT), lds, s, a, vec4); break;                 \
+    default: hipLaunchKernelGGL((conv_small_cout_kernel<PROV, 4>), g, dim3(kSmallBT), lds, s, a, vec4); break;                \
   }
     switch (a.prologue) {
       case PRO_NONE: PH_SMALL(PRO_NONE) break;
