@@ -427,6 +427,31 @@ def main():
                 "hbm_side": {"algorithmic_GBps": round(m_by / (m_us * 1e-6) / 1e9, 1) if m_us > 0 else 0.0, "peak": HBM_PEAK_GBS},
                 "share_of_utterance_gpu_time": round(m_us / (float(np.mean(gpu_ms)) * 1e3), 3),
             }
+            # the same measurement per kernel family (each member launch replayed as its own graph): the lumped figure above
+            # is dominated by the ≈ 60 short-row launches of the encoder and the flow, which sit on the launch floor
+            def fam_of(name):
+                if "pair_x3" in name or "ab_lrelu_conv" in name:
+                    return "rb_pair_kernel (generator ResBlock conv pairs)"
+                if "convT" in name:
+                    return "conv_win/conv_pipe (generator ConvTranspose)"
+                if "rb" in name and name.startswith("dec."):
+                    return "conv_win/conv_pipe (generator ResBlock convs, one conv per launch)"
+                if name.startswith("dec."):
+                    return None
+                return "conv_stream_kernel (encoder + flow convs)"
+            fams = {}
+            for st in conv:
+                f = fam_of(st["name"])
+                if f is None or bf16:
+                    continue
+                us1, n1, fl1, _ = rt.time_subset(0, st["name"], iters=10)
+                e = fams.setdefault(f, {"launches": 0, "us": 0.0, "flops": 0.0})
+                e["launches"] += n1; e["us"] += us1 * n1; e["flops"] += fl1
+            out["roofline_by_kernel"] = [
+                {"kernel": f, "launches": e["launches"], "avg_launch_us": round(e["us"] / max(1, e["launches"]), 2), "gflop": round(e["flops"] / 1e9, 3),
+                 "achieved": round(e["flops"] / (e["us"] * 1e-6) / 1e12, 2) if e["us"] > 0 else 0.0, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(e["flops"] / (e["us"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if e["us"] > 0 else 0.0}
+                for f, e in sorted(fams.items(), key=lambda kv: -kv[1]["us"])]
             all_fl = sum(s["flops"] for s in stats)
             out["utterance_roofline"] = {
                 "algorithmic_gflop": round(all_fl / 1e9, 3), "t_min_ms_at_fp32_mfma_peak": round(all_fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 4),

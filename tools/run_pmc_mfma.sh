@@ -1,7 +1,7 @@
 #!/bin/bash
 # MFMA-busy evidence (north-star: "MFMA-busy against gfx950 peak"): separate PMC passes, kernel-trace not combined.
 set -e
-TAG=${1:-r1c}
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
