@@ -223,10 +223,14 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
   const int n = blockIdx.y;
   const int mt_eff = GATE ? mtiles / 2 : mtiles;
   const int tile = (int)blockIdx.x * WT + tw;
-  const bool active = tile < mt_eff * nchunks;
-  const int mt = active ? tile % mt_eff : 0;
-  const int chunk = active ? tile / mt_eff : 0;
+  const bool in_grid = tile < mt_eff * nchunks;
+  const int mt = in_grid ? tile % mt_eff : 0;
+  const int chunk = in_grid ? tile / mt_eff : 0;
   const int t0 = chunk * TM * NT;
+  // Bucketed / ragged batches: a tile whose every column lies at or past the item's TRUE length computes nothing anyone reads
+  // (consumers mask by the same length) — 'same'-length convs and ConvTranspose (GEMM columns = input positions) only
+  const bool past_len = p.len_ptr && (p.Lout == p.Lin || p.epilogue == EPI_CONVT) && t0 >= true_len(p, n);
+  const bool active = in_grid && !past_len;
   const int j = lane & (TM - 1), kk = lane / TM;
   const int ncp = (p.Cin + CPS - 1) / CPS;  // channel units (pairs / quads)
   const int nsteps = ngroups * S;  // packed steps per row tile (zero-padded to whole groups)

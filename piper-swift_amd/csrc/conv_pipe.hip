@@ -161,7 +161,19 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
     }
   };
 
-  int t = blockIdx.x;
+  // Bucketed / ragged batches: a tile whose columns all lie at or past its item's TRUE length computes nothing anyone reads;
+  // the block steps over such tiles (its tile sequence is t, t + G, …: next_live keeps that stride), so the pipeline below only
+  // ever sees live tiles.
+  auto next_live = [&](int tt) {
+    while (tt < ntiles) {
+      const TileInfo ti = decode(tt);
+      const ConvWinArgs& p = multi.c[ti.j];
+      if (!p.len_ptr || ti.cb * NBC < min(p.len_ptr[ti.n] * p.len_mul, p.Lin)) break;
+      tt += gridDim.x;
+    }
+    return tt;
+  };
+  int t = next_live(blockIdx.x);
   if (t >= ntiles) return;
   TileInfo cur = decode(t);
 
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
   // ---- prologue: first chunk of the first tile
   issue(cur, 0);
   {
-    const int tn = t + gridDim.x;
+    const int tn = next_live(t + gridDim.x);
     if (tn < ntiles) wa_next = tile_wbase(decode(tn));
   }
 #pragma unroll
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
     const int off0 = ct ? (rho + p.ct_pad) / p.ct_stride : -p.padL;  // window position of tap t: off0 + t·dstep
     const int dstep = ct ? -1 : p.dil;
     const int lbase = h * Wp + shift + wn * NTW * 32 + r - off_min + off0;
-    const int tn = t + gridDim.x;
+    const int tn = next_live(t + gridDim.x);
     const bool has_next = tn < ntiles;
     const TileInfo nxt = has_next ? decode(tn) : cur;
 
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
     wa_cur = wa_next;
     G = tile_groups(cur);
     {
-      const int tnn = t + gridDim.x;
+      const int tnn = next_live(t + gridDim.x);
       wa_next = tnn < ntiles ? tile_wbase(decode(tnn)) : wa_cur;
     }
   }

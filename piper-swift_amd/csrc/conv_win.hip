@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
   const int C2 = p.Cin >> 1;
   const int n = blockIdx.z % batch;
   const int nb0 = blockIdx.x * NBC;
+  // bucketed / ragged batches: every column of this block at or past the item's true length ⇒ nothing anyone reads (block-uniform)
+  if (p.len_ptr && nb0 >= min(p.len_ptr[n] * p.len_mul, p.Lin)) return;
   const int mt = blockIdx.y * WM + wm;
   const int off_min = ct ? -(taps - 1) : -p.padL;
   const int off_max = ct ? (p.ct_stride - 1 + p.ct_pad) / p.ct_stride : (p.K - 1) * p.dil - p.padL;

@@ -55,21 +55,33 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   const int t = t0 + col;
   float y[kMaxRows];
   float s1 = 0.0f;
+  // every load is unconditional (clamped address, value masked afterwards): with the loads inside the range tests the
+  // compiler waits for each one before the next test — 18 dependent round trips, 22 µs per layer at T = 112 (r2 profile)
+  float xv[kMaxRows][KD], wv[kMaxRows][KD], bv[kMaxRows], g1v[kMaxRows], b1v[kMaxRows];
+#pragma unroll
+  for (int i = 0; i < kMaxRows; i++) {
+    const int c = min(crow + 32 * i, H - 1);
+    bv[i] = dw_b[c];
+    g1v[i] = g1[c];
+    b1v[i] = b1[c];
+#pragma unroll
+    for (int k = 0; k < KD; k++) {
+      const int pos = t + (k - (KD - 1) / 2) * dil;
+      xv[i][k] = xb[(int64_t)c * T + min(max(pos, 0), T - 1)];
+      wv[i][k] = dw_w[c * KD + k];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
     const int c = crow + 32 * i;
-    y[i] = 0.0f;
-    if (c < H) {
-      float acc = dw_b[c];  // bias first, then the taps in order (CPUBackend.conv1d with Cin/g = 1)
+    float acc = bv[i];  // bias first, then the taps in order (CPUBackend.conv1d with Cin/g = 1)
 #pragma unroll
-      for (int k = 0; k < KD; k++) {
-        const int pos = t + (k - (KD - 1) / 2) * dil;
-        const float xv = (pos >= 0 && pos < Tv) ? xb[(int64_t)c * T + pos] : 0.0f;
-        acc += xv * dw_w[c * KD + k];
-      }
-      y[i] = acc;
-      s1 += acc;
+    for (int k = 0; k < KD; k++) {
+      const int pos = t + (k - (KD - 1) / 2) * dil;
+      acc += ((pos >= 0 && pos < Tv) ? xv[i][k] : 0.0f) * wv[i][k];
     }
+    y[i] = c < H ? acc : 0.0f;
+    s1 += y[i];
   }
   // ---- 2. LayerNorm over the channels of each column (two passes, like the graph) → GELU → act
   red[crow * 16 + col] = s1;
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
     const int c = crow + 32 * i;
-    if (c < H) act[c * 16 + col] = gelu_erf((y[i] / sd) * g1[c] + b1[c]);
+    if (c < H) act[c * 16 + col] = gelu_erf((y[i] / sd) * g1v[i] + b1v[i]);
   }
   __syncthreads();
   // ---- 3. pointwise conv on the tile: D[row = channel][col]; wave ↔ row tiles wave, wave + 8
@@ -117,15 +129,23 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[r] = pw_b[min(16 * mt + 4 * kq + r, H - 1)];
       const float* wa = pw16 + (int64_t)mt * pw_steps * 64 + lane;
-      for (int s0 = 0; s0 < nst; s0 += 8) {
-        float a[8], b[8];
+      // weight fragments two batches of 16 steps ahead of the MFMAs that use them (the batches used to alternate load → wait → multiply)
+      float a[2][16];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = wa[min(s0 + u, pw_steps - 1) * 64];
+      for (int u = 0; u < 16; u++) a[0][u] = wa[min(u, pw_steps - 1) * 64];
+      for (int s0 = 0; s0 < nst; s0 += 32) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) b[u] = act[min(4 * (s0 + u) + kq, H - 1) * 16 + r16];
+        for (int half = 0; half < 2; half++) {
+          const int sb = s0 + 16 * half;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (s0 + u < nst) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], 4 * (s0 + u) + kq < H ? b[u] : 0.0f, acc, 0, 0, 0);
+          for (int u = 0; u < 16; u++) a[half ^ 1][u] = wa[min(sb + 16 + u, pw_steps - 1) * 64];
+          float b[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) b[u] = act[min(4 * (sb + u) + kq, H - 1) * 16 + r16];
+#pragma unroll
+          for (int u = 0; u < 16; u++)
+            if (sb + u < nst) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[half][u], 4 * (sb + u) + kq < H ? b[u] : 0.0f, acc, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -166,17 +186,26 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   for (int q = 0; q < kW; q++) var2 += red[q * 16 + r16];
   var2 = var2 / (float)H;
   const float sd2 = sqrtf(var2 + eps);
-  if (t0 + r16 < Tv) {
+  {
+    const int tc = min(t0 + r16, T - 1);
+    float g2v[kMaxTiles][4], b2v[kMaxTiles][4], xr[kMaxTiles][4];  // loads first (clamped), masked stores after
+#pragma unroll
+    for (int ti = 0; ti < kMaxTiles; ti++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = min(16 * (wave + kW * ti) + 4 * kq + r, H - 1);
+        g2v[ti][r] = g2[c];
+        b2v[ti][r] = b2[c];
+        xr[ti][r] = xb[(int64_t)c * T + tc];
+      }
 #pragma unroll
     for (int ti = 0; ti < kMaxTiles; ti++) {
       const int mt = wave + kW * ti;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int c = 16 * mt + 4 * kq + r;
-        if (mt < ntiles && c < H) {
-          const float hid = gelu_erf((val[ti][r] / sd2) * g2[c] + b2[c]);
-          ob[(int64_t)c * T + t0 + r16] = xb[(int64_t)c * T + t0 + r16] + hid;
-        }
+        const float hid = gelu_erf((val[ti][r] / sd2) * g2v[ti][r] + b2v[ti][r]);
+        if (t0 + r16 < Tv && mt < ntiles && c < H) ob[(int64_t)c * T + t0 + r16] = xr[ti][r] + hid;
       }
     }
   }

@@ -274,15 +274,18 @@ __global__ __launch_bounds__(MT * kWN * 64, 2) void rb_pair_kernel(const RbPairM
     PH_STAMP(1);
     if (has_next) stage_issue(nxt, tx);  // next tile's window: in flight during conv a, held in registers through conv b
 
+    // bucketed / ragged batches: a tile at or past the item's true length is skipped — its barriers and the next tile's
+    // prefetch / commit stay (block-uniform)
+    const bool live = cur.c0 < cur.Lv;
     // ======== conv a: x1 columns [c0 − halo, c0 − halo + 256) = tiles wn·2, wn·2 + 1 of the tile's 8
-    run_conv(std::integral_constant<int, kNTW>{}, xs, Wx, cur.Sa, cur.Spa, cur.dila, cur.shift + wn * kNTW * 32, cur.bias_off);
+    if (live) run_conv(std::integral_constant<int, kNTW>{}, xs, Wx, cur.Sa, cur.Spa, cur.dila, cur.shift + wn * kNTW * 32, cur.bias_off);
     PH_STAMP(2);
-    ring_start(cur.wb4, cur.Spb);  // conv b's ring: its round trip hides behind the x1 epilogue and the barriers
-    if (cur.res_a) load_res(cur.c0 - cur.halo);
+    if (live) ring_start(cur.wb4, cur.Spb);  // conv b's ring: its round trip hides behind the x1 epilogue and the barriers
+    if (live && cur.res_a) load_res(cur.c0 - cur.halo);
     __syncthreads();               // every wave is done reading the x window: its memory now takes the raw x1
     PH_STAMP(3);
 
-    {  // x1 = [x +] acc (bias inside), zero outside [0, len): lrelu(x1) → x1s (conv b's operand), raw x1 → xs region (ResBlock2's
+    if (live) {  // x1 = [x +] acc (bias inside), zero outside [0, len): lrelu(x1) → x1s (conv b's operand), raw x1 → xs region (ResBlock2's
        // residual). register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r
 #pragma unroll
       for (int j = 0; j < kNTW; j++) {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(MT * kWN * 64, 2) void rb_pair_kernel(const RbPairM
 
     PH_STAMP(4);
     // ======== conv b: the tile's output tiles, two per wave column (the last ones get one or none)
-    if (cur.ntb > 0) {
+    if (live && cur.ntb > 0) {
       const int col0b = cur.halo - cur.pb + wn * kNTW * 32;
       __builtin_amdgcn_s_waitcnt(0x0F70);
       if (cur.ntb == 2) run_conv(std::integral_constant<int, 2>{}, x1s, W1, cur.Sb, cur.Spb, cur.dilb, col0b, cur.bias_off + C);
@@ -313,8 +316,8 @@ __global__ __launch_bounds__(MT * kWN * 64, 2) void rb_pair_kernel(const RbPairM
     }
     PH_STAMP(5);
     if (has_next) ring_start(nxt.wa4, nxt.Spa);  // next tile's conv a ring: lands during the epilogue and the barriers
-    if (cur.res_b_x && cur.ntb > 0) load_res(cur.c0);
-    if (cur.ntb > 0) {  // y = acc (bias inside) + (x | x1) → global; 2 rows × 32 consecutive columns per store instruction
+    if (live && cur.res_b_x && cur.ntb > 0) load_res(cur.c0);
+    if (live && cur.ntb > 0) {  // y = acc (bias inside) + (x | x1) → global; 2 rows × 32 consecutive columns per store instruction
       const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)cur.y, 0, C * cur.L * 4, 0x00020000);
 #pragma unroll
       for (int j = 0; j < kNTW; j++) {
