@@ -31,6 +31,9 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
                          int64_t out_batch_stride, const int* len_ptr);
 size_t dp_scalars_bytes(int n);
 void dp_scalars_fill(void* host, int i, float noise_w, float length_scale, unsigned gen, unsigned seed);
+bool flow_seam_eligible(int H, int half);
+int launch_flow_seam(hipStream_t s, const float* skip, float* zp, float* h, const float* post16, const float* post_b, const float* pre16,
+                     const float* pre_b, int N, int H, int half, int F, int post_steps, int pre_steps, int ob, int os, const int* len_ptr);
 bool dds_layer_eligible(int H, int K);
 int launch_dds_layer(piper_hip_ctx* ctx, hipStream_t s, const float* x, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
                      const float* pw16, const float* pw_b, const float* g2, const float* b2, float* out, int N, int H, int T, int K, int dil,
@@ -187,6 +190,8 @@ struct Slot {
   int32_t* dp_dur = nullptr;   // [NB][T] predicted frames per id
   std::vector<int32_t> h_dur;  // predicted durations of the attached request, per item back to back (host)
   int* h_lens = nullptr;       // pinned staging [2·NB]
+  float* h_audio = nullptr;    // pinned landing buffer of the waveform (collect: device → pinned DMA, then a host memcpy)
+  size_t h_audio_cap = 0;
   size_t h_cap_lens = 0;
   // device buffers
   std::vector<void*> owned;
@@ -491,7 +496,8 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
     if (s.h_ids) (void)hipHostFree(s.h_ids);
     if (s.h_f2i) (void)hipHostFree(s.h_f2i);
     if (s.h_lens) (void)hipHostFree(s.h_lens);
-    s.h_ids = nullptr; s.h_f2i = nullptr; s.h_lens = nullptr; s.h_cap_t = s.h_cap_f = s.h_cap_lens = 0;
+    if (s.h_audio) (void)hipHostFree(s.h_audio);
+    s.h_ids = nullptr; s.h_f2i = nullptr; s.h_lens = nullptr; s.h_audio = nullptr; s.h_cap_t = s.h_cap_f = s.h_cap_lens = 0; s.h_audio_cap = 0;
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
     if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
@@ -1184,7 +1190,14 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
     flipped = !flipped;
     const auto& C = v->flows[f];
     const std::string p = "flow" + std::to_string(f) + ".";
-    {
+    // post of this coupling + x1 − m + Flip + pre of the next one in ONE launch (flow_seam.hip); PIPER_HIP_NO_FLOW_SEAM=1 keeps them apart
+    static const bool no_seam = getenv("PIPER_HIP_NO_FLOW_SEAM") != nullptr;
+    auto seam_ok = [&](const piper_hip_voice::Coupling& A, const piper_hip_voice::Coupling& B) {
+      return !no_seam && I == 2 * half && flow_seam_eligible(H, half) && A.post.w16 && B.pre.w16 && A.post.bias && B.pre.bias && A.post.K == 1 && B.pre.K == 1 &&
+             A.post.Cin == H && A.post.Cout == half && B.pre.Cin == half && B.pre.Cout == H;
+    };
+    const bool pre_done = f + 1 < c.n_flows && seam_ok(v->flows[f + 1], C);  // the previous (f + 1) coupling's seam already wrote h
+    if (!pre_done) {
       ConvArgs a = plain(zp, h, I, H, F, lensF);
       a.in_ch_base = flipped ? I - 1 : 0;
       a.in_ch_sign = flipped ? -1 : 1;
@@ -1203,7 +1216,20 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
       else { b.epilogue = EPI_WN_RES_SKIP; b.wn_c = H; b.res = h; }
       add_conv(v, s, p + "wn" + std::to_string(i) + ".res_skip", C.rs[i], b, F);
     }
-    {
+    if (f > 0 && seam_ok(C, v->flows[f - 1])) {
+      const auto& Nx = v->flows[f - 1];
+      Step st;
+      st.name = p + "post_sub_flip_pre" + std::to_string(f - 1);
+      st.tag = "conv_mfma";
+      const float *p16 = C.post.w16, *pb = C.post.bias, *q16 = Nx.pre.w16, *qb = Nx.pre.bias;
+      const int ps = (int)(packed_conv_floats(half, H, 1, 16) / ((size_t)ceil_div(half, 16) * 64));
+      const int qs = (int)(packed_conv_floats(H, half, 1, 16) / ((size_t)ceil_div(H, 16) * 64));
+      const int ob = flipped ? I - 1 - half : half, os = flipped ? -1 : 1;
+      st.run = [=](hipStream_t q) { return launch_flow_seam(q, skip, zp, h, p16, pb, q16, qb, NB, H, half, F, ps, qs, ob, os, lensF); };
+      st.flops = NB * (conv_flops(half, H, 1, F) + conv_flops(H, half, 1, F));
+      st.bytes = NB * 4.0 * ((double)H * F + 2.0 * half * F + (double)H * F + 2.0 * half * H);
+      s.steps.push_back(st);
+    } else {
       ConvArgs a = plain(skip, zp, H, I, F, lensF);
       a.epilogue = EPI_RSUB;
       a.res = zp;
@@ -2057,13 +2083,28 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     int64_t total = 0;  // batch items back to back, each at its own true length
     for (int b = 0; b < s.NB; b++) total += (int64_t)s.h_F[b] * v->hop;
     if (max_samples < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)total);
+    // A copy into the caller's (pageable) buffer goes through the runtime's own staging in chunks and its time varies from
+    // box to box (r2z: 45 … 130 µs for 344 KB). Up to 64 MB the waveform lands in a pinned buffer of the plan by one DMA and is
+    // copied out by the host.
+    constexpr size_t kPinnedMax = (size_t)64 << 20;
+    const size_t bytes = (size_t)total * sizeof(float);
+    if (bytes <= kPinnedMax && s.h_audio_cap < bytes) {
+      if (s.h_audio) (void)hipHostFree(s.h_audio);
+      s.h_audio = nullptr; s.h_audio_cap = 0;
+      if (hipHostMalloc((void**)&s.h_audio, bytes) == hipSuccess) s.h_audio_cap = bytes;
+      else { s.h_audio = nullptr; (void)hipGetLastError(); }
+    }
+    float* dst = (bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
     int64_t off = 0;
     for (int b = 0; b < s.NB; b++) {
       const int64_t nb = (int64_t)s.h_F[b] * v->hop;
-      PH_HIP(hipMemcpyAsync(host_audio + off, s.audio + (int64_t)b * s.n_samples, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, s.stream),
+      PH_HIP(hipMemcpyAsync(dst + off, s.audio + (int64_t)b * s.n_samples, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, s.stream),
              PIPER_HIP_ERR_LAUNCH);
       off += nb;
     }
+    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    if (dst != host_audio) memcpy(host_audio, dst, bytes);
+    return PIPER_HIP_OK;
   }
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;
