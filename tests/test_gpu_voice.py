@@ -53,6 +53,23 @@ def test_ragged_durations(rt_medium, golden_mods):
     assert_close(audio, golden_mods["synth_ragged.audio"], WAVE_TOL)
 
 
+def test_gather_semantics_of_out_of_range_ids(rt_medium, voices):
+    """gather_axis0_f32_2d (gather.metal:44-58) / CPUBackend.gather: a negative id wraps once (+n_vocab), what is still out of range
+    gathers a zero vector — the embedding kernel and the oracle both follow it."""
+    cfg, blob = voices["medium"]
+    ids = [1, -1, 20, cfg.n_vocab + 5, -cfg.n_vocab, 2, -cfg.n_vocab - 3]
+    dur = [2] * len(ids)
+    noise = kd.sym(SD + 90, (cfg.inter, sum(dur)), 1.7320508)
+    audio, taps = run_with_taps(rt_medium, ids, dur, noise)
+    ref_audio, ref_taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+    assert_close(taps["enc_out"], ref_taps["enc_out"], OP_TOL, "enc_out with wrapped / out-of-range ids")
+    assert_close(audio, ref_audio, WAVE_TOL)
+    # the oracle's side of the rule, stated on its own: −1 ≡ n_vocab − 1 and −n_vocab ≡ 0 give the same encoder output
+    a1 = orc.text_encoder(cfg, blob, [1, -1, 20, -cfg.n_vocab, 2])[0]
+    a2 = orc.text_encoder(cfg, blob, [1, cfg.n_vocab - 1, 20, 0, 2])[0]
+    assert np.array_equal(a1, a2)
+
+
 def test_synthesize_api_and_no_noise(rt_medium, voices):
     cfg, blob = voices["medium"]
     ids, dur = [1, 20, 0, 120, 2], [2, 1, 3, 1, 2]
