@@ -30,7 +30,9 @@ public final class PiperHIPRuntime {
         try HIPBackend.check(piper_hip_onnx_build_blob(model, &cfg, &blob, n))
         try HIPBackend.check(piper_hip_voice_create(backend.ctx, &cfg, blob, 0, &voice))
         sampleRate = cfg.sample_rate
-        hop = Int(cfg.hop)
+        var h = 1                                                              // hop = Π upsample rates (256 for Piper)
+        withUnsafeBytes(of: &cfg.up_rates) { r in for i in 0..<Int(cfg.n_ups) { h *= Int(r.load(fromByteOffset: 4 * i, as: Int32.self)) } }
+        hop = h
     }
     deinit { piper_hip_voice_destroy(voice) }
 
