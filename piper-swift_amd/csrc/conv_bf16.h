@@ -66,4 +66,24 @@ int launch_conv_bf16(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args& a);
 constexpr int kBf16Multi = 3;
 int launch_conv_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args* convs, int count);
 
+// ---- rb_pair_bf16.hip: a ResBlock1 pair  y = x + conv_b(lrelu(conv_a(lrelu(x)) + ba)) + bb  in one kernel (C ∈ {32, 64, 128},
+// odd kernels, conv b reaching ≤ 16 positions); x / y fp32 [N][C][L], weights = the fragment images above
+struct RbPairBf16Args {
+  const float* x = nullptr;
+  float* y = nullptr;            // must not alias x; may be null when only `act` is wanted
+  const float* mrf_a = nullptr;  // both set: the result becomes ((mrf_a + mrf_b) + y) / 3 — the MRF mean over the stage's ResBlocks
+  const float* mrf_b = nullptr;
+  uint16_t* act = nullptr;       // optional C8 image of lrelu(result, alpha) [N][C/8][act_row][8] for a consumer that is not fused
+  int act_row = 0;
+  const uint16_t *wa = nullptr, *wb = nullptr;
+  const float *ba = nullptr, *bb = nullptr;
+  int Ka = 1, dila = 1, Kb = 1, dilb = 1;
+  float alpha = 0.1f;
+  int N = 1, C = 0, L = 0;       // L % 4 == 0
+  const int* len_ptr = nullptr;  // true length of item n = len_ptr[n]·len_mul; null ⇒ L
+  int len_mul = 1;
+};
+bool rb_pair_bf16_eligible(int C, int Ka, int dila, int Kb, int dilb, int L);
+int launch_rb_pair_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const RbPairBf16Args* pairs, int count);  // ≤ 3 pairs, same N, C, L
+
 }  // namespace ph

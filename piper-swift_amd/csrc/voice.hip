@@ -699,6 +699,47 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
           src[j] = dst;
           src_act[j] = dst_act;
         }
+        // ResBlock1 pairs that are not the stage's last: both convs in one launch, intermediate in LDS (rb_pair_bf16.hip)
+        static const bool no_pair = getenv("PIPER_HIP_NO_RB_PAIR") != nullptr;
+        if (c.resblock_type == 1 && !no_pair) {
+          struct Pack { RbPairBf16Args a[3]; } pk;
+          bool ok = true;
+          for (int j = 0; j < 3 && ok; j++) {
+            RbPairBf16Args& q = pk.a[j];
+            q.x = bb[j].res; q.y = bb[j].y;
+            // fused pairs stage from the fp32 stream themselves; the stage's last pair writes the next stage's input image, and a
+            // pair in front of an UNFUSED one writes the image that one reads
+            const bool next_fused = !lastd && rb_pair_bf16_eligible(S.Cout, c.rb_kernels[j], c.rb_dilations[j][di + 1], c.rb_kernels[j], 1, Lo);
+            q.act = (lastd || !next_fused) ? bb[j].act : nullptr;
+            q.mrf_a = bb[j].mrf_a; q.mrf_b = bb[j].mrf_b;
+            q.act_row = row;
+            q.wa = wa[j]->w; q.ba = wa[j]->bias; q.wb = wb[j]->w; q.bb = wb[j]->bias;
+            q.Ka = wa[j]->K; q.dila = aa[j].dil; q.Kb = wb[j]->K; q.dilb = 1; q.alpha = 0.1f;
+            q.N = NB; q.C = S.Cout; q.L = Lo; q.len_ptr = s.lensF; q.len_mul = Lo / F;
+            ok = q.x && (q.y || q.act) && q.wa && q.wb && q.ba && q.bb && wa[j]->Cin == S.Cout && wa[j]->Cout == S.Cout && wb[j]->Cin == S.Cout && wb[j]->Cout == S.Cout &&
+                 rb_pair_bf16_eligible(S.Cout, q.Ka, q.dila, q.Kb, q.dilb, Lo);
+          }
+          if (ok) {
+            piper_hip_ctx* ctx = v->ctx;
+            auto add_pairs = [&](const std::string& name, int first, int count, double flops) {
+              struct P2 { RbPairBf16Args a[3]; } p2;
+              for (int i = 0; i < 3; i++) p2.a[i] = pk.a[first + (i < count ? i : 0)];
+              Step st;
+              st.name = name;
+              st.tag = "conv_bf16";
+              st.flops = 2.0 * flops;
+              st.bytes = NB * count * (2.0 * 4.0 * S.Cout * (double)Lo);
+              st.run = [ctx, p2, count](hipStream_t q) { return launch_rb_pair_bf16_multi(ctx, q, p2.a, count); };
+              s.steps.push_back(std::move(st));
+            };
+            if (!lastd) add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_x3", 0, 3, fl[0] + fl[1] + fl[2]);
+            else {  // rb2's pair folds the MRF mean over r0, r1: it runs after theirs
+              add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_x2", 0, 2, fl[0] + fl[1]);
+              add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_mrfmean", 2, 1, fl[2]);
+            }
+            continue;
+          }
+        }
         if (c.resblock_type == 1) add_conv_bf16_multi(v, s, nm + "a_lrelu_conv_x3", wa, aa, 3, fl[0] + fl[1] + fl[2]);
         const std::string bn = c.resblock_type == 1 ? "b" : "";
         if (!lastd) {
