@@ -57,6 +57,10 @@ int pack_convt_weights_bf16(hipStream_t s, const float* w, int Cin, int Cout, in
 int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha, uint16_t* act, int64_t row = 0,
                 const int* len_ptr = nullptr);  // positions ≥ len_ptr[n] are written as zeros
 
+// C8 image of lrelu(((a + b) + c) / 3, alpha) — the MRF mean of three fp32 [N][C][L] tensors (true length of item n = len_ptr[n]·len_mul)
+int pack_mean3_c8(hipStream_t s, const float* a, const float* b, const float* c, int N, int C, int L, float alpha, uint16_t* act, int64_t row,
+                  const int* len_ptr, int len_mul);
+
 // geometry the bf16 kernels cover (stride-1, ungrouped, Cin % 32 == 0, padding within the halo)
 bool conv_bf16_eligible(int Cout, int Cin, int K, int dil, int padL, int padR);
 bool convt_bf16_eligible(int Cin, int Cout, int K, int stride, int padL, int padR, int dil, int out_pad);

@@ -85,6 +85,30 @@ __global__ __launch_bounds__(kBT) void pack_act_c8_kernel(const float* __restric
   }
 }
 
+// C8 image of lrelu(((a + b) + c) / 3, alpha): the MRF mean of a stage's three ResBlock outputs as the next stage's input
+__global__ __launch_bounds__(kBT) void pack_mean3_c8_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int C,
+                                                           int L, int64_t row, float alpha, uint16_t* __restrict__ act, const int* __restrict__ len_ptr,
+                                                           int len_mul) {
+  const int CB = (C + 7) >> 3;
+  const int n = blockIdx.z, cb = blockIdx.y;
+  const int Lv = len_ptr ? min(len_ptr[n] * len_mul, L) : L;
+  const int64_t off = ((int64_t)n * C + cb * 8) * L;
+  uint4* ab = (uint4*)act + ((int64_t)n * CB + cb) * row + kC8Halo;
+  for (int pos = blockIdx.x * kBT + threadIdx.x; pos < L; pos += gridDim.x * kBT) {
+    float va[8], vb[8], vc[8], v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int64_t i = off + (int64_t)min(e, C - cb * 8 - 1) * L + pos;
+      va[e] = a[i]; vb[e] = b[i]; vc[e] = c[i];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (cb * 8 + e < C && pos < Lv) ? lrelu1(((va[e] + vb[e]) + vc[e]) / 3.0f, alpha) : 0.0f;
+    uint4 o;
+    o.x = pack2_bf16(v[0], v[1]); o.y = pack2_bf16(v[2], v[3]); o.z = pack2_bf16(v[4], v[5]); o.w = pack2_bf16(v[6], v[7]);
+    ab[pos] = o;
+  }
+}
+
 // ---------------------------------------------------------------- the conv
 // WM waves along rows × (4/WM) along columns; each wave MTW × NTW tiles of 32×32.
 struct ConvBf16Multi {
@@ -342,6 +366,15 @@ int pack_act_c8(hipStream_t s, const float* x, int N, int C, int L, float alpha,
   if (row <= 0) row = c8_row_len(L);
   const dim3 grid((unsigned)std::min<int64_t>(ceil_div(L, kBT), 1024), (unsigned)((C + 7) / 8), (unsigned)N);
   hipLaunchKernelGGL(pack_act_c8_kernel, grid, dim3(kBT), 0, s, x, C, L, row, alpha, act, len_ptr);
+  return PIPER_HIP_OK;
+}
+
+int pack_mean3_c8(hipStream_t s, const float* a, const float* b, const float* c, int N, int C, int L, float alpha, uint16_t* act, int64_t row,
+                  const int* len_ptr, int len_mul) {
+  if (N <= 0 || C <= 0 || L <= 0) return PIPER_HIP_OK;
+  if (row == 0) row = c8_row_len(L);
+  const dim3 grid((unsigned)std::min<int64_t>(ceil_div(L, kBT), 1024), (unsigned)((C + 7) / 8), (unsigned)N);
+  hipLaunchKernelGGL(pack_mean3_c8_kernel, grid, dim3(kBT), 0, s, a, b, c, C, L, row, alpha, act, len_ptr, len_mul);
   return PIPER_HIP_OK;
 }
 

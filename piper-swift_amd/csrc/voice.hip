@@ -733,9 +733,27 @@ int build_generator_bf16(piper_hip_voice* v, Slot& s, Arena& ar, const float* z,
               s.steps.push_back(std::move(st));
             };
             if (!lastd) add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_x3", 0, 3, fl[0] + fl[1] + fl[2]);
-            else {  // rb2's pair folds the MRF mean over r0, r1: it runs after theirs
-              add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_x2", 0, 2, fl[0] + fl[1]);
-              add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_mrfmean", 2, 1, fl[2]);
+            else {
+              // all three last pairs in one launch (rb2 writes its own fp32 output), then the MRF mean as a small elementwise
+              // launch: a single pair of a 128-channel stage is 96 blocks for 256 CUs (52 µs; r3h), the mean 8 µs
+              pk.a[2].y = r[2]; pk.a[2].act = nullptr; pk.a[2].mrf_a = nullptr; pk.a[2].mrf_b = nullptr;
+              add_pairs(nm + "ab_lrelu_conv_lrelu_conv_res_x3", 0, 3, fl[0] + fl[1] + fl[2]);
+              Step st;
+              st.name = p + "mrf_mean" + (last_stage ? "" : "_lrelu_to_bf16");
+              const float *r0 = r[0], *r1 = r[1], *r2 = r[2];
+              const int* lf = s.lensF;
+              const int Cc = S.Cout, lm = Lo / F;
+              if (last_stage) {  // conv_post applies its LeakyReLU(0.01) itself: slope 1 here
+                const int64_t cnt = (int64_t)NB * S.Cout * Lo;
+                st.run = [=](hipStream_t q) {
+                  const int grid = (int)std::min<int64_t>(ceil_div(cnt, (int64_t)kBlock * 4), 2048);
+                  hipLaunchKernelGGL(mrf_mean_lrelu_kernel, dim3(grid), dim3(kBlock), 0, q, r0, r1, r2, m, cnt, 1.0f);
+                  return PIPER_HIP_OK;
+                };
+              } else {
+                st.run = [=](hipStream_t q) { return pack_mean3_c8(q, r0, r1, r2, NB, Cc, Lo, 0.1f, a_next, row, lf, lm); };
+              }
+              s.steps.push_back(st);
             }
             continue;
           }
