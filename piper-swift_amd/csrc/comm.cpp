@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -29,8 +31,21 @@ Rccl& rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must drive the SAME copy of the HIP runtime this library does: a process may hold two (PyTorch bundles its own
+    // libamdhip64 + librccl next to ROCm's), and a librccl bound to the other copy sees "no ROCm-capable device" (r3k). So the
+    // first candidates are the librccl files that sit next to the libamdhip64 our own HIP calls resolve to.
+    std::string dir;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      dir = info.dli_fname;
+      const size_t slash = dir.rfind('/');
+      dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+    }
+    std::vector<std::string> names;
+    if (!dir.empty()) { names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
+    names.push_back("librccl.so.1"); names.push_back("librccl.so"); names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string& name : names) {
+      r.h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (r.h) break;
     }
     if (!r.h) { r.why = "librccl.so.1 not found (dlopen)"; return; }
