@@ -2143,9 +2143,10 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     for (int b = 0; b < s.NB; b++) total += (int64_t)s.h_F[b] * v->hop;
     if (max_samples < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: buffer holds %lld < %lld samples", (long long)max_samples, (long long)total);
     // A copy into the caller's (pageable) buffer goes through the runtime's own staging in chunks and its time varies from
-    // box to box (r2z: 45 … 130 µs for 344 KB). Up to 64 MB the waveform lands in a pinned buffer of the plan by one DMA and is
-    // copied out by the host.
-    constexpr size_t kPinnedMax = (size_t)64 << 20;
+    // box to box (r2z: 45 … 130 µs for 344 KB). Up to 1 MB (a factor-8 … 16 utterance) the waveform lands in a pinned buffer of
+    // the plan by one DMA and is copied out by the host; beyond that the runtime's pipelined chunks beat DMA + memcpy
+    // (factor 64, 2.75 MB: +0.12 ms with the pinned hop).
+    constexpr size_t kPinnedMax = (size_t)1 << 20;
     const size_t bytes = (size_t)total * sizeof(float);
     if (bytes <= kPinnedMax && s.h_audio_cap < bytes) {
       if (s.h_audio) (void)hipHostFree(s.h_audio);
