@@ -1,7 +1,9 @@
 /* synth_demo.c — the C-ABI used from plain C, the way a Swift/C/C++ host binds it:
  *   create context → synthetic voice (or a Piper .onnx) → one utterance → 16-bit WAV.
  * build: gcc -std=c99 -Iinclude examples/synth_demo.c -Lpiper-swift_amd/lib -lpiper_hip -Wl,-rpath,$PWD/piper-swift_amd/lib -o synth_demo
- * run:   ./synth_demo out.wav [factor] [voice.onnx]
+ * run:   ./synth_demo out.wav [factor] [voice.onnx | -] [predict]
+ *        `predict`: frames per id from the voice's duration predictor and both noise tensors drawn on the device (seed 1234) —
+ *        PiperMetalRuntime.synthesize(phonemeIDs:noiseScale:lengthScale:noiseW:) — instead of 3 pinned frames per id and zero noise
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +23,8 @@
 int main(int argc, char** argv) {
   const char* out = argc > 1 ? argv[1] : "out.wav";
   const int factor = argc > 2 ? atoi(argv[2]) : 1;
-  const char* onnx = argc > 3 ? argv[3] : NULL;
+  const char* onnx = (argc > 3 && strcmp(argv[3], "-") != 0) ? argv[3] : NULL;
+  const int predict = argc > 4 && strcmp(argv[4], "predict") == 0;
   static const int64_t fixture[14] = {1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2}; /* bench/fixtures/test_summary.json:8 */
 
   piper_hip_voice_config cfg;
@@ -55,11 +58,23 @@ int main(int argc, char** argv) {
   piper_hip_utterance u;
   memset(&u, 0, sizeof u);
   u.phoneme_ids = ids; u.t = T; u.durations = dur; u.noise = NULL; u.noise_scale = 0.667f;
-  const int64_t n = piper_hip_voice_num_samples(voice, &u);
-  if (n <= 0) { fprintf(stderr, "bad utterance: %s\n", piper_hip_last_error()); return 1; }
-  float* audio = (float*)malloc(sizeof(float) * (size_t)n);
-  int64_t got = 0;
-  CHECK(piper_hip_voice_synthesize(voice, &u, audio, n, &got));
+  int64_t n = 0, got = 0;
+  float* audio = NULL;
+  if (predict) {
+    u.durations = NULL; u.noise_mode = PIPER_HIP_NOISE_DEVICE; u.seed = 1234; u.length_scale = 1.0f; u.noise_w = 0.8f;
+    int rcp = piper_hip_voice_prepare(voice, &u, 0); /* runs the duration predictor, uploads the inputs */
+    if (rcp < 0) { fprintf(stderr, "prepare failed (%d): %s\n", rcp, piper_hip_last_error()); return 1; }
+    CHECK(piper_hip_voice_prepared_samples(voice, 0, NULL, 0, &n));
+    audio = (float*)malloc(sizeof(float) * (size_t)n);
+    CHECK(piper_hip_voice_launch(voice, 0));
+    CHECK(piper_hip_voice_collect(voice, 0, audio, n));
+    got = n;
+  } else {
+    n = piper_hip_voice_num_samples(voice, &u);
+    if (n <= 0) { fprintf(stderr, "bad utterance: %s\n", piper_hip_last_error()); return 1; }
+    audio = (float*)malloc(sizeof(float) * (size_t)n);
+    CHECK(piper_hip_voice_synthesize(voice, &u, audio, n, &got));
+  }
   double ms = 0.0;
   CHECK(piper_hip_voice_last_gpu_ms(voice, 0, &ms));
   CHECK(piper_hip_wav_write(out, audio, (size_t)got, cfg.sample_rate));

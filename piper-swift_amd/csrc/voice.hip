@@ -190,6 +190,8 @@ struct Slot {
   int32_t* dp_dur = nullptr;   // [NB][T] predicted frames per id
   std::vector<int32_t> h_dur;  // predicted durations of the attached request, per item back to back (host)
   int* h_lens = nullptr;       // pinned staging [2·NB]
+  hipEvent_t ev_in = nullptr;  // kind 3: "the copy of the predictor plan's projection has been read" (that plan's stream waits for it)
+  float* stats = nullptr;      // [NB][2·inter][T] encoder projection (m_p ; logs_p): output of kinds 0 / 2, INPUT of kind 3
   float* h_audio = nullptr;    // pinned landing buffer of the waveform (collect: device → pinned DMA, then a host memcpy)
   size_t h_audio_cap = 0;
   size_t h_cap_lens = 0;
@@ -497,6 +499,8 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
     if (s.h_f2i) (void)hipHostFree(s.h_f2i);
     if (s.h_lens) (void)hipHostFree(s.h_lens);
     if (s.h_audio) (void)hipHostFree(s.h_audio);
+    if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+    s.ev_in = nullptr;
     s.h_ids = nullptr; s.h_f2i = nullptr; s.h_lens = nullptr; s.h_audio = nullptr; s.h_cap_t = s.h_cap_f = s.h_cap_lens = 0; s.h_audio_cap = 0;
     if (s.ev0) (void)hipEventDestroy(s.ev0);
     if (s.ev1) (void)hipEventDestroy(s.ev1);
@@ -1039,9 +1043,12 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
 // the duration predictor on the encoder output x [NB][H][T]: → s.dp_dur / "logw" tap
 int build_duration_predictor(piper_hip_voice* v, Slot& s, Arena& ar, const float* x, int T, int NB);
 
-// mode 0: whole utterance; 1: generator only (streaming window); 2: text encoder + duration predictor
+// mode 0: whole utterance; 1: generator only (streaming window); 2: text encoder + projection + duration predictor;
+// 3: everything AFTER the text encoder (expansion, flow, generator) from an m_p / logs_p tensor copied in from a mode-2 plan —
+// the pair (2, 3) is a whole utterance with predicted durations that runs the encoder once
 int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode = 0) {
   const bool gen_only = mode == 1;
+  const bool from_stats = mode == 3;
   const piper_hip_voice_config& c = v->cfg;
   piper_hip_ctx* ctx = v->ctx;
   const int H = c.hidden, I = c.inter, d = H / c.n_heads;
@@ -1101,6 +1108,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   float* skip = ar.f32(B * (size_t)H * F);
   dec0 = ar.f32(B * (size_t)c.up_initial * F);
   if (ar.rc) return ar.rc;
+  s.stats = stats;
+  if (!from_stats) {
   {
     Step st;
     st.name = "embed";
@@ -1216,12 +1225,14 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
       };
       s.steps.push_back(st);
     }
+    add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T, lensT), T);  // kept for the mode-3 plan that continues from here
     return build_duration_predictor(v, s, ar, x, T, NB);
   }
   if (ln_ok && c.n_layers > 0)
     add_conv(v, s, "enc.ln2_proj", v->proj, with_ln(plain(y, stats, H, 2 * I, T, lensT), st2, v->enc[c.n_layers - 1].g2, v->enc[c.n_layers - 1].b2, x), T);
   else
   add_conv(v, s, "enc.proj", v->proj, plain(x, stats, H, 2 * I, T, lensT), T);
+  }  // !from_stats
   s.taps["m_p"] = {stats, I, T, 0, (size_t)2 * I * T};  // halves of the [2I, T] projection
   s.taps["logs_p"] = {stats + (size_t)I * T, I, T, 0, (size_t)2 * I * T};
   {
@@ -1891,6 +1902,10 @@ void detach(piper_hip_voice* v, int slot) {
 
 }  // namespace
 
+namespace {
+int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out, int max_entries, Slot** plan_out);
+}
+
 PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot) {
   if (!v || !utts) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
   if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
@@ -1903,6 +1918,11 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   // the predicted frames per id exactly as if the caller had supplied them
   std::vector<piper_hip_utterance> resolved;
   std::vector<int32_t> predicted;
+  Slot* dp_plan = nullptr;  // the encoder + predictor plan whose m_p / logs_p the main plan continues from (kind 3: no second encoder pass)
+  struct DpRelease {
+    Slot*& p;
+    ~DpRelease() { if (p) p->in_use = false; }
+  } dp_release{dp_plan};
   {
     bool any_null = false;
     for (int b = 0; b < n; b++) any_null = any_null || (utts[b].phoneme_ids && !utts[b].durations);
@@ -1913,7 +1933,7 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
         total += utts[b].t;
       }
       predicted.resize((size_t)total);
-      if ((rc = piper_hip_voice_predict_durations(v, utts, n, predicted.data(), nullptr, (int)total))) return rc;
+      if ((rc = predict_impl(v, utts, n, predicted.data(), nullptr, (int)total, &dp_plan))) return rc;
       resolved.assign(utts, utts + n);
       int64_t off = 0;
       for (int b = 0; b < n; b++) {
@@ -1942,11 +1962,12 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   if ((int64_t)F * v->hop * n > 0x3fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch too large");
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   Slot* cur = v->attached[slot];
-  const bool same = cur && cur->exec && cur->kind == 0 && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
+  const int kind = (dp_plan && dp_plan->stats && dp_plan->T == T && dp_plan->NB == n) ? 3 : 0;
+  const bool same = cur && cur->exec && cur->kind == kind && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
   if (cur && !same) detach(v, slot);
   if (!same) {
     bool built = false;
-    if ((rc = acquire_plan(v, 0, T, F, n, &cur, &built))) return rc;
+    if ((rc = acquire_plan(v, kind, T, F, n, &cur, &built))) return rc;
     cur->in_use = true;
     v->attached[slot] = cur;
     evict_idle_plans(v);
@@ -1955,6 +1976,15 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   s.last_use = ++v->use_clock;
   // the previous launch on this plan may still be reading the inputs
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  if (kind == 3)  // the predictor's plan has finished (predict synchronises): its projection becomes this plan's input
+  {
+    PH_HIP(hipMemcpyAsync(s.stats, dp_plan->stats, (size_t)n * 2 * I * T * sizeof(float), hipMemcpyDeviceToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+    // the predictor plan goes back to the cache when this function returns: whatever runs on it next must not overwrite the
+    // projection before this copy has read it
+    if (!s.ev_in) PH_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(hipEventRecord(s.ev_in, s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(hipStreamWaitEvent(dp_plan->stream, s.ev_in, 0), PIPER_HIP_ERR_LAUNCH);
+  }
   s.st_next = -1;
   s.h_T = hT;
   s.h_F = hF;
@@ -2009,8 +2039,17 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   return slot;
 }
 
+namespace {
+int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out, int max_entries, Slot** plan_out);
+}
 PH_EXPORT int piper_hip_voice_predict_durations(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out,
                                                 int max_entries) {
+  return predict_impl(v, utts, n, durations_out, logw_out, max_entries, nullptr);
+}
+namespace {
+// plan_out (optional): the encoder + predictor plan that ran, left marked in_use so that its m_p / logs_p stay put until the caller
+// has enqueued the copy into the plan that continues from them (the caller clears in_use)
+int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out, int max_entries, Slot** plan_out) {
   if (!v || !utts || !durations_out) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
   if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
   if (!v->cfg.dp_present) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice has no duration predictor (dp_present = 0)");
@@ -2059,7 +2098,8 @@ PH_EXPORT int piper_hip_voice_predict_durations(piper_hip_voice* v, const piper_
   if (e == hipSuccess) e = hipMemcpyAsync(dur.data(), s.dp_dur, dur.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
   if (e == hipSuccess && logw_out) e = hipMemcpyAsync(lw.data(), s.taps["logw"].p, lw.size() * sizeof(float), hipMemcpyDeviceToHost, s.stream);
   if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
-  s.in_use = false;
+  if (plan_out && e == hipSuccess) *plan_out = pl;  // stays in_use: see above
+  else s.in_use = false;
   evict_idle_plans(v);
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "predict_durations: %s", hipGetErrorString(e));
   int64_t off = 0;
@@ -2070,6 +2110,7 @@ PH_EXPORT int piper_hip_voice_predict_durations(piper_hip_voice* v, const piper_
   }
   return PIPER_HIP_OK;
 }
+}  // namespace
 
 PH_EXPORT int piper_hip_voice_prepared_samples(const piper_hip_voice* v, int slot, int64_t* per_item, int max_items, int64_t* total) {
   const Slot* p = slot_plan(v, slot);

@@ -427,6 +427,38 @@ def test_c_host_program_end_to_end(rt_medium, tmp_path):
         assert w.getframerate() == 22050 and w.getnframes() == ref.size
         got = np.frombuffer(w.readframes(ref.size), "<i2")
     assert np.array_equal(got, ref)
+    # the same host with the durations predicted and the noise drawn on the device (ids are all it supplies)
+    wav2 = tmp_path / "c_host_predict.wav"
+    out = subprocess.run([str(exe), str(wav2), "2", "-", "predict"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rt_medium.prepare(3, ids, None, None, 0.667, noise_mode="device", seed=1234, length_scale=1.0, noise_w=0.8)
+    rt_medium.launch(3)
+    ref2 = ph.pcm16(rt_medium.collect(3))
+    with wave.open(str(wav2), "rb") as w:
+        assert w.getnframes() == ref2.size
+        assert np.array_equal(np.frombuffer(w.readframes(ref2.size), "<i2"), ref2)
+
+
+def test_bf16_fused_pairs_equal_the_two_launch_path(tmp_path):
+    """rb_pair_bf16_kernel against conv_bf16_kernel × 2 (PIPER_HIP_NO_RB_PAIR is read once per process, so: two child processes):
+    the rounding points are the same, what differs is fp32 summation order and the bf16 roundings it flips — mutual SNR ≥ 45 dB and
+    each side ≥ 40 dB against the fp32 oracle on a bucketed (non-multiple) length."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "probe", "bf16_pair_ab.py")
+    a, b = str(tmp_path / "fused.npy"), str(tmp_path / "unfused.npy")
+    env = dict(os.environ)
+    env.pop("PIPER_HIP_NO_RB_PAIR", None)
+    subprocess.check_call([sys.executable, tool, "run", a], env=env, timeout=300)
+    subprocess.check_call([sys.executable, tool, "run", b], env=dict(env, PIPER_HIP_NO_RB_PAIR="1"), timeout=300)
+    out = subprocess.run([sys.executable, tool, "cmp", a, b], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import re
+    snrs = [float(x) for x in re.findall(r"SNR(?: vs fp32 oracle)? ([0-9.]+) dB", out.stdout)]
+    assert len(snrs) == 3 and snrs[0] >= 45.0 and min(snrs[1:]) >= 40.0, snrs
 
 
 @pytest.mark.parametrize("quality,factor,chunk", [("medium", 8, 64), ("medium", 8, 50), ("medium", 1, 64), ("high", 4, 32)])

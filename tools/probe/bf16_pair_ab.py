@@ -48,3 +48,4 @@ else:
     for name, x in (("fused", a), ("unfused", b)):
         y = x[-ref.size:].astype(np.float64)
         print(f"  {name}: SNR vs fp32 oracle {10 * np.log10((ref ** 2).sum() / ((y - ref) ** 2).sum()):.1f} dB, max|Δ| {np.abs(y - ref).max():.3e}")
+    sys.exit(0 if np.isfinite(a).all() and np.isfinite(b).all() else 1)
