@@ -245,9 +245,11 @@ def main():
     plan0 = rt.plan_info(0)
     rt.prepare(0, ids, dur, noise, 0.667)
 
+    out_buf = rt.pinned_empty(n_samples)  # page-locked destination (piper_hip_host_alloc): the D2H of the waveform is one DMA
+
     def step():
         rt.launch(0)
-        return rt.collect(0)
+        return rt.collect(0, out=out_buf)
 
     for _ in range(args.warmup):
         step()

@@ -75,6 +75,11 @@ int piper_hip_upload_f32(piper_hip_ctx* ctx, const float* host, size_t count, fl
 int piper_hip_upload_i64(piper_hip_ctx* ctx, const int64_t* host, size_t count, int64_t** out);
 /* MetalBackend.downloadFloat32 (MetalBackend.swift:963-981): blocks until `buf` is complete. */
 int piper_hip_download_f32(piper_hip_ctx* ctx, const float* buf, float* host, size_t count);
+/* Page-locked host memory — the analogue of reading `MTLBuffer.contents()` of a shared-storage buffer (MetalBackend.swift:963-981 copies out
+ * of one): piper_hip_voice_collect / piper_hip_download_f32 into such a buffer is a single DMA, without the staging copy a pageable
+ * destination needs. Plain malloc'ed buffers keep working everywhere. */
+int piper_hip_host_alloc(piper_hip_ctx* ctx, size_t bytes, void** out);
+int piper_hip_host_free(piper_hip_ctx* ctx, void* host);
 /* MetalBackend.makeCommandBuffer / flush / flushWithTimings (MetalBackend.swift:841-874). */
 int piper_hip_stream_create(piper_hip_ctx* ctx, piper_hip_stream* out);
 int piper_hip_stream_destroy(piper_hip_ctx* ctx, piper_hip_stream s);

@@ -250,6 +250,28 @@ PH_EXPORT int piper_hip_upload_i64(piper_hip_ctx* ctx, const int64_t* host, size
   return PIPER_HIP_OK;
 }
 
+PH_EXPORT int piper_hip_host_alloc(piper_hip_ctx* ctx, size_t bytes, void** out) {
+  PH_CHECK_CTX(ctx);
+  if (!out) PH_FAIL(PIPER_HIP_ERR_ARG, "host_alloc: null out");
+  *out = nullptr;
+  if (bytes == 0) return PIPER_HIP_OK;
+  if (hipHostMalloc(out, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    PH_FAIL(PIPER_HIP_ERR_ALLOC, "host_alloc: %zu bytes of page-locked memory not available", bytes);
+  }
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_host_free(piper_hip_ctx* ctx, void* host) {
+  PH_CHECK_CTX(ctx);
+  if (host && hipHostFree(host) != hipSuccess) {
+    (void)hipGetLastError();
+    PH_FAIL(PIPER_HIP_ERR_ARG, "host_free: not a pointer returned by piper_hip_host_alloc");
+  }
+  return PIPER_HIP_OK;
+}
+
 PH_EXPORT int piper_hip_download_f32(piper_hip_ctx* ctx, const float* buf, float* host, size_t count) {
   PH_CHECK_CTX(ctx);
   if ((!buf || !host) && count) PH_FAIL(PIPER_HIP_ERR_ARG, "null pointer");

@@ -2189,13 +2189,20 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     // (factor 64, 2.75 MB: +0.12 ms with the pinned hop).
     constexpr size_t kPinnedMax = (size_t)1 << 20;
     const size_t bytes = (size_t)total * sizeof(float);
-    if (bytes <= kPinnedMax && s.h_audio_cap < bytes) {
+    // a destination the caller page-locked itself (piper_hip_host_alloc) takes the DMA directly
+    bool caller_pinned = false;
+    {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, host_audio) == hipSuccess) caller_pinned = at.type == hipMemoryTypeHost;
+      else (void)hipGetLastError();
+    }
+    if (!caller_pinned && bytes <= kPinnedMax && s.h_audio_cap < bytes) {
       if (s.h_audio) (void)hipHostFree(s.h_audio);
       s.h_audio = nullptr; s.h_audio_cap = 0;
       if (hipHostMalloc((void**)&s.h_audio, bytes) == hipSuccess) s.h_audio_cap = bytes;
       else { s.h_audio = nullptr; (void)hipGetLastError(); }
     }
-    float* dst = (bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
+    float* dst = (!caller_pinned && bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
     int64_t off = 0;
     for (int b = 0; b < s.NB; b++) {
       const int64_t nb = (int64_t)s.h_F[b] * v->hop;

@@ -196,6 +196,8 @@ _PROTOS = {
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
     "piper_hip_voice_num_samples": (C.c_int64, [c_vp, C.POINTER(Utterance)]),
+    "piper_hip_host_alloc": (C.c_int, [c_vp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "piper_hip_host_free": (C.c_int, [c_vp, C.c_void_p]),
     "piper_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "piper_hip_comm_create": (C.c_int, [c_vp, C.c_void_p, C.c_int, C.c_int, C.POINTER(c_vp)]),
     "piper_hip_comm_destroy": (None, [c_vp]),
@@ -755,11 +757,15 @@ class HipRuntime:
         _check(self.lib.piper_hip_voice_create(backend.ctx, C.byref(cfg), ptr, int(on_device), C.byref(v)))
         self.voice = v
         self._keep = {}
+        self._pinned = []
 
     def close(self):
         if self.voice:
             self.lib.piper_hip_voice_destroy(self.voice)
             self.voice = None
+        for p in self._pinned:
+            self.lib.piper_hip_host_free(self.backend.ctx, p)
+        self._pinned = []
 
     def set_precision(self, precision):
         """"f32" (default, the parity configuration) or "bf16" (generator convs on bf16 operands, fp32 accumulate)."""
@@ -876,12 +882,21 @@ class HipRuntime:
     def launch(self, slot):
         _check(self.lib.piper_hip_voice_launch(self.voice, slot))
 
-    def collect(self, slot, want_audio=True):
+    def pinned_empty(self, count):
+        """float32 array in page-locked host memory (piper_hip_host_alloc): `collect(slot, out=…)` into it is one DMA. Freed by close()."""
+        p = C.c_void_p()
+        _check(self.lib.piper_hip_host_alloc(self.backend.ctx, int(count) * 4, C.byref(p)))
+        self._pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, c_f32p), shape=(int(count),))
+
+    def collect(self, slot, want_audio=True, out=None):
         n = self._keep[slot][1]
         if not want_audio:
             _check(self.lib.piper_hip_voice_collect(self.voice, slot, None, 0))
             return None
-        out = np.empty(max(n, 1), np.float32)
+        if out is None:
+            out = np.empty(max(n, 1), np.float32)
+        assert out.dtype == np.float32 and out.size >= n and out.flags.c_contiguous
         _check(self.lib.piper_hip_voice_collect(self.voice, slot, out.ctypes.data_as(c_f32p), n))
         return out[:n]
 

@@ -70,6 +70,20 @@ def test_gather_semantics_of_out_of_range_ids(rt_medium, voices):
     assert np.array_equal(a1, a2)
 
 
+def test_collect_into_page_locked_buffer(rt_medium):
+    """piper_hip_host_alloc: collect() into a page-locked destination (direct DMA) returns the same samples as into a pageable one."""
+    ids, dur = kd.FIXTURE_IDS * 2, [3] * 28
+    noise = kd.sym(SD + 91, (192, sum(dur)), 1.7320508)
+    rt_medium.prepare(5, ids, dur, noise, 0.667)
+    rt_medium.launch(5)
+    a = rt_medium.collect(5).copy()
+    buf = rt_medium.pinned_empty(a.size + 7)
+    buf[:] = -2.0
+    rt_medium.launch(5)
+    b = rt_medium.collect(5, out=buf)
+    assert np.array_equal(a, b) and np.all(buf[a.size:] == -2.0)
+
+
 def test_synthesize_api_and_no_noise(rt_medium, voices):
     cfg, blob = voices["medium"]
     ids, dur = [1, 20, 0, 120, 2], [2, 1, 3, 1, 2]
