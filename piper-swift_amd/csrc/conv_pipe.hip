@@ -79,7 +79,7 @@ struct TileInfo {  // wave-uniform description of one tile (all scalars)
 
 template <int WM, int WN, int NTW, bool AVG>
 __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi, const int count, const int batch, const int ntiles,
-                                                       const int col_blocks, const int row_groups, const int Wp) {
+                                                       const int col_blocks, const int row_groups, const int Wp, const int order) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int NBC = WN * NTW * 32;  // columns per tile
   constexpr int NX = AVG ? 3 : 1;
@@ -96,10 +96,21 @@ __global__ __launch_bounds__(kBT, 2) void conv_pipe_kernel(const PipeMulti multi
   const int st_row0 = tid / W4, st_c40 = tid - st_row0 * W4;
   const int st_dr = kBT / W4, st_dc = kBT - st_dr * W4;
 
-  auto decode = [&](int t) {
+  // Tile order. The launch's convs differ in taps (a ResBlock stage: kernels 3 / 7 / 11), i.e. in cost per tile. Tiles are ranked
+  // heaviest conv first; a block's sequence number e = blockIdx.x + m·gridDim.x is cut into HALF-rounds of gridDim.x / 2: even
+  // half-rounds take from the heavy end of the ranking, odd ones from the light end. Blocks b and b + gridDim.x / 2 are the two
+  // a CU holds, so each CU gets a heavy and a light tile instead of two of a kind (r3: the 256-channel stage of the high voice
+  // at factor 8 is 504 tiles for 512 block slots — one tile per block, 121 µs with k = 7 and k = 11 sharing CUs).
+  const int tpc = col_blocks * row_groups * batch;  // tiles per conv
+  const int half_g = max((int)gridDim.x >> 1, 1);
+  auto decode = [&](int e) {
+    const int hr = e / half_g, b = e - hr * half_g;
+    int i = (hr & 1) ? ntiles - 1 - (hr >> 1) * half_g - b : (hr >> 1) * half_g + b;  // rank, heaviest first
+    i = __builtin_amdgcn_readfirstlane(min(max(i, 0), ntiles - 1));
+    const int z = i / tpc;  // position in the cost order
+    int rest = i - z * tpc;
     TileInfo ti;
-    ti.j = t % count;
-    int rest = t / count;
+    ti.j = (order >> (4 * z)) & 15;
     ti.cb = rest % col_blocks;
     rest /= col_blocks;
     ti.rg = rest % row_groups;
@@ -499,6 +510,12 @@ int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs*
   const int grid = (int)std::min<int64_t>(ntiles, (int64_t)ctx->num_cus * per_cu);
   PipeMulti multi;
   for (int i = 0; i < kWinMulti; i++) multi.c[i] = convs[i < count ? i : 0];
+  int ord[kWinMulti] = {0, 1, 2}, order = 0;  // convs by taps, heaviest first (tile cost ∝ taps)
+  std::sort(ord, ord + count, [&](int l, int r2) {
+    const int tl = convs[l].ct_stride > 0 ? convs[l].K / convs[l].ct_stride : convs[l].K, tr = convs[r2].ct_stride > 0 ? convs[r2].K / convs[r2].ct_stride : convs[r2].K;
+    return tl > tr;
+  });
+  for (int i = 0; i < count; i++) order |= ord[i] << (4 * i);
 #define PH_PIPE_CASE(M, N_, T_)                                                                                                        \
   if (g.WM == M && g.WN == N_ && g.NTW == T_) {                                                                                        \
     if (avg) {                                                                                                                         \
@@ -506,13 +523,13 @@ int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs*
         static bool raised[kMaxDevices] = {};                                                                                          \
         if (lds > 64 * 1024 && lds_optin_needed(raised))                                                                               \
           (void)hipFuncSetAttribute((const void*)conv_pipe_kernel<M, N_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((conv_pipe_kernel<M, N_, 1, true>), dim3(grid), dim3(kBT), lds, s, multi, count, a.N, ntiles, col_blocks, row_groups, Wp); \
+        hipLaunchKernelGGL((conv_pipe_kernel<M, N_, 1, true>), dim3(grid), dim3(kBT), lds, s, multi, count, a.N, ntiles, col_blocks, row_groups, Wp, order); \
       }                                                                                                                                \
     } else {                                                                                                                           \
       static bool raised[kMaxDevices] = {};                                                                                            \
       if (lds > 64 * 1024 && lds_optin_needed(raised))                                                                                 \
         (void)hipFuncSetAttribute((const void*)conv_pipe_kernel<M, N_, T_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      hipLaunchKernelGGL((conv_pipe_kernel<M, N_, T_, false>), dim3(grid), dim3(kBT), lds, s, multi, count, a.N, ntiles, col_blocks, row_groups, Wp); \
+      hipLaunchKernelGGL((conv_pipe_kernel<M, N_, T_, false>), dim3(grid), dim3(kBT), lds, s, multi, count, a.N, ntiles, col_blocks, row_groups, Wp, order); \
     }                                                                                                                                  \
   } else
   PH_PIPE_CASE(4, 1, 1) PH_PIPE_CASE(4, 1, 2) PH_PIPE_CASE(2, 2, 1) PH_PIPE_CASE(2, 2, 2) PH_PIPE_CASE(1, 4, 1) PH_PIPE_CASE(1, 4, 2)
