@@ -70,6 +70,14 @@ __global__ __launch_bounds__(kBT) void pack_convt_win_kernel(const float* __rest
   }
 }
 
+// tools/probe/winprobe -DPH_WIN_TRACE: s_memtime stamps at the phase boundaries (per wave of the first 1024 blocks)
+#ifdef PH_WIN_TRACE
+__device__ unsigned long long* ph_win_trace_buf;
+#define PH_WSTAMP(k) do { const int bl_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if ((threadIdx.x & 63) == 0 && ph_win_trace_buf && bl_ < 1024) ph_win_trace_buf[((size_t)bl_ * 4 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_WSTAMP(k) do { } while (0)
+#endif
+
 // WM waves along rows × WN along columns × KS along the contraction; WM·WN·KS = 4. One 32×32 tile per wave.
 struct ConvWinMulti {
   ConvWinArgs c[kWinMulti];
@@ -81,6 +89,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
   const ConvWinArgs& p = multi.c[blockIdx.z / batch];  // wave-uniform: which of the launch's convs this block works on
   static_assert(WM * WN * KS == 4, "4 waves per block");
   constexpr int NBC = WN * 32;
+  PH_WSTAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ks = wave / (WM * WN), wt = wave % (WM * WN);
@@ -123,28 +132,30 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
     const float* xb2 = AVG ? p.x2 + xoff : nullptr;
     const float* xb3 = AVG ? p.x3 + xoff : nullptr;
     const int W4 = Wp >> 2;              // float4s per row
-    const int WCH = (W4 + 63) >> 6;
-    const int dump = p.Cin * Wp;         // lanes past the row end / rows past Cin store here (keeps the loads unconditional)
+    const int total4 = p.Cin * W4;
+    const int dump = p.Cin * Wp;         // slots past the window store here (keeps the loads unconditional)
     const int Lv = p.len_ptr ? min(p.len_ptr[n] * p.len_mul, p.Lin) : p.Lin;  // true input length of this batch item
-    int row = wave, chunk = 0;
-    while (row < p.Cin) {
+    // FLAT slot index over (row, float4 column): slot i ↔ row = i / W4 by a multiply-high (exact: i·W4 < 2^32). The window of a
+    // ConvTranspose tile or of a short-dilation conv is 10 … 20 float4 wide — walking it row by row with 64 lanes per row left
+    // 10/64 of every load instruction useful and cost 4 … 13 dependent round trips (r3s trace: 23 k … 70 k cycles of staging
+    // against 9 k … 22 k of MFMAs); flat, a thread's kStage slots cover the block's window in one or two.
+    const unsigned inv = 0xFFFFFFFFu / (unsigned)W4 + 1u;
+    for (int base = threadIdx.x; base < total4; base += kBT * kStage) {
       float4 t[kStage], t2[AVG ? kStage : 1], t3[AVG ? kStage : 1];
       int dst[kStage];
       int nvalid[kStage];
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
-        const int rr = min(row, p.Cin - 1);
-        const int i4 = chunk * 64 + lane;
+        const int i = base + q * kBT;
+        const int ic = min(i, total4 - 1);
+        const int row = (int)__umulhi((unsigned)ic, inv);
+        const int i4 = ic - row * W4;
         const int pos = ga + 4 * i4;     // multiple of 4; the row stride is a multiple of 4, the true length need not be
         nvalid[q] = pos < 0 ? 0 : Lv - pos;  // leading components inside [0, Lv) (≥ 4: all of them)
-        const int64_t off = (int64_t)rr * p.Lin + ((pos >= 0 && pos < p.Lin) ? pos : 0);
+        const int64_t off = (int64_t)row * p.Lin + ((pos >= 0 && pos < p.Lin) ? pos : 0);
         t[q] = *(const float4*)(xb + off);
         if constexpr (AVG) { t2[q] = *(const float4*)(xb2 + off); t3[q] = *(const float4*)(xb3 + off); }
-        dst[q] = (row < p.Cin && i4 < W4) ? rr * Wp + 4 * i4 : dump;
-        chunk++;
-        const bool wrap = chunk == WCH;
-        chunk = wrap ? 0 : chunk;
-        row += wrap ? 4 : 0;
+        dst[q] = i < total4 ? row * Wp + 4 * i4 : dump;
       }
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
@@ -159,9 +170,12 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
       }
     }
   };
+  PH_WSTAMP(1);
   if (p.x2) stage(std::true_type{});
   else stage(std::false_type{});
+  PH_WSTAMP(2);
   __syncthreads();
+  PH_WSTAMP(3);
 
   f32x16 acc;
 #pragma unroll
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
       if (u < rem) group(u);
   }
 
+  PH_WSTAMP(4);
   if constexpr (KS > 1) {  // slice 0 + slice 1 + … in fixed order
     __syncthreads();       // every wave is done reading the window: its memory becomes the exchange area
     float* red = win;
@@ -238,6 +253,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
     }
   }
 
+  PH_WSTAMP(5);
   // ---- epilogue. register q of lane (r,h): row (q&3) + 8·(q>>2) + 4·h, column r. Loads first (clamped), stores masked.
   const int rows_total = ct ? p.Cout * p.ct_stride : p.Cout;
   const int row0 = mt * 32;
@@ -272,6 +288,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
 #pragma unroll
   for (int q = 0; q < 16; q++)
     if (okc && co0 + (q & 3) + 8 * (q >> 2) + 4 * h < p.Cout) p.y[yi[q]] = lrelu1(v[q], p.out_alpha);
+  PH_WSTAMP(6);
 }
 
 template <int WM, int WN, int KS>
@@ -304,6 +321,10 @@ size_t lds_bytes(int Cin, int wn, int reach, int ks, int wmwn) {
 }
 
 }  // namespace
+
+#ifdef PH_WIN_TRACE
+void conv_win_set_trace(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ph_win_trace_buf), &buf, sizeof buf); }
+#endif
 
 size_t packed_conv_win_floats(int Cout, int Cin, int K) { return (size_t)((Cout + 31) / 32) * padded_steps_win(Cin, K) * 64 + kTailFloats; }
 size_t packed_convt_win_floats(int Cin, int Cout, int K, int stride) {

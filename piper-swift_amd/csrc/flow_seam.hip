@@ -6,7 +6,7 @@
 //   m      = W_post · skip + b_post                (half rows, K = H)
 //   x1new  = x1 − m            → zp (in place, through the coupling's channel map) and → LDS
 //   h'     = W_pre' · x1new + b_pre'               (H rows, K = half; logical input channel c = half − 1 − r: the Flip)
-// with no global round trip in between — one launch (≈ 8 µs at these sizes, DESIGN §4 finding 8) less per coupling boundary.
+// with no global round trip in between — one launch (≈ 8 µs at these sizes, DESIGN §4 finding 9) less per coupling boundary.
 // fp32 on v_mfma_f32_16x16x4_f32, weights from the 16-wide fragment images the streaming kernel uses.
 #include "common.h"
 
