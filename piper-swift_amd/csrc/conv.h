@@ -49,6 +49,7 @@ struct ConvArgs {
   float alpha = 0.0f;
   int epilogue = EPI_STORE;
   int gate = 0;  // MFMA path: Cout = 2·H rows; emits H rows tanh(a)·sigmoid(b)
+  unsigned long long* trace = nullptr;  // tools/probe/streamprobe (-DPH_STREAM_TRACE): s_memtime stamps per wave; unused otherwise
   int wn_c = 0;  // EPI_WN_RES_SKIP split point
   // ConvTranspose (EPI_CONVT): GEMM rows = Cout_ct·ct_stride, GEMM cols = q
   int ct_stride = 0, ct_padL = 0, ct_Lout = 0;

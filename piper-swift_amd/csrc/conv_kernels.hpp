@@ -205,6 +205,12 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 // buffer_load with an SGPR offset.  Zero padding inside a row is a per-lane bit mask computed once per tile and only
 // on tiles that touch a row edge.  Groups of G·K steps are double-buffered in registers (loads of group g+1 are in
 // flight while group g feeds the matrix pipe).
+#ifdef PH_STREAM_TRACE
+#define PH_SSTAMP(k) do { if (p.trace && lane == 0 && blockIdx.x < 512 && blockIdx.y == 0) p.trace[((size_t)blockIdx.x * 16 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_SSTAMP(k) do { } while (0)
+#endif
+
 template <int K, int NT, bool GATE, int PRO, int BT, int TM>
 __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const int nchunks, const int mtiles, const int ks_log2,
                                                          const int ngroups) {
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
   extern __shared__ __attribute__((aligned(16))) float red[];  // [KS-1][WT][NA][NT][NR][64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  PH_SSTAMP(0);
   const int KS = 1 << ks_log2;
   const int WT = (BT / 64) >> ks_log2;
   const int tw = wave >> ks_log2, ks = wave & (KS - 1);
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     }
   }
 
+  PH_SSTAMP(1);
   if (active) {
     const int g_begin = (int)(((int64_t)ngroups * ks) >> ks_log2), g_end = (int)(((int64_t)ngroups * (ks + 1)) >> ks_log2);
     const int xbytes = (int)(p.x_batch_stride * 4);
@@ -330,6 +338,9 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
           }
       };
       constexpr int regs_per_group = S * (NA + NX * NT) + (PRO == PRO_LN ? 2 * G : 0);
+      // D = 2 above 256 threads. (A deeper ring there — so that a wave's 3–4 groups are all in flight before its first MFMA — was
+      // measured: the flow's gated conv stayed at 13.4 µs, the FFN's second conv went 12.9 → 16.7 µs. These launches are bound by the
+      // ISSUE of their fragment loads, ≈ 100 cycles each with 8–16 waves per CU on the address path, not by dependent round trips.)
       constexpr int D = BT > 256 ? 2 : (regs_per_group * 4 <= 112 ? 4 : (regs_per_group * 3 <= 132 ? 3 : 2));
       float av[D][NA][S], bv[D][NX][S][NT];
       float lng[PRO == PRO_LN ? D : 1][G], lnb[PRO == PRO_LN ? D : 1][G];  // gamma / beta of this lane's channel per channel unit
@@ -392,6 +403,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       if (g_begin < g_end) {
         const int g_last = g_end - 1;
         static_for<D - 1>([&](auto d) { fetch(d, min(g_begin + d.value, g_last)); });
+        PH_SSTAMP(5);
         // the statistics are requested BEHIND the first operand groups: one memory round trip covers both
         if constexpr (PRO == PRO_LN) load_ln_stats();
         for (int g = g_begin; g < g_end; g += D) {
@@ -399,6 +411,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
             const int gg = g + d.value;
             fetch(std::integral_constant<int, (d.value + D - 1) % D>{}, min(gg + D - 1, g_last));
             if (gg < g_end) compute(d, gg);
+            if (d.value == 0 && g == g_begin) PH_SSTAMP(6);
           });
         }
       }
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     else body(std::true_type{});
   }
 
+  PH_SSTAMP(2);
   if (KS > 1) {  // fixed-order reduction over the contraction slices: slice 0 + slice 1 + … (deterministic)
     constexpr int per_wave = NA * NT * NR * 64;
     if (ks > 0) {
@@ -432,6 +446,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     }
   }
 
+  PH_SSTAMP(3);
   if (!active || ks != 0) return;
   const int rows_out = GATE ? p.Cout / 2 : p.Cout;
   auto emit = [&](auto mode_tag) {
@@ -487,6 +502,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
     case EPI_CONVT: emit(std::integral_constant<int, EPI_CONVT>{}); break;
     case EPI_MRF_MEAN: emit(std::integral_constant<int, EPI_MRF_MEAN>{}); break;
   }
+  PH_SSTAMP(4);
 }
 
 // ======================================================================================================
