@@ -203,9 +203,13 @@ __global__ __launch_bounds__(kSmallBT) void conv_small_cout_kernel(const ConvArg
 // output). Here a thread owns FOUR consecutive outputs: per channel 4 aligned ds_read_b128 give the 4 + K − 1 window values,
 // 2 broadcast ds_read_b128 the taps — 6 LDS reads per 28 FMAs instead of 56 — and the window is staged 8 channels at a time as
 // float4s with the NEXT chunk's loads (≤ 27 per thread) in flight under the current chunk's arithmetic.
-constexpr int kWideBT = 256, kWideOut = 4 * kWideBT, kWideCK = 8, kWideW = kWideOut + 16, kWideK = 7, kWidePad = 3;
-template <int PRO>
-__global__ __launch_bounds__(kWideBT) void conv_cout1_wide_kernel(const ConvArgs p) {
+// The block size is a template parameter: 256 threads (1024 outputs) for long rows; ONE wave (256 outputs) when 1024-output blocks
+// would leave most CUs without one (a factor-8 utterance is 84 of them): r2, 24.8 → 22.7 µs there, 26.1 → 20.2 µs at factor 1.
+// (Two chunks of loads in flight instead of one was also measured: no gain on short rows, 61 → 83 µs at factor 64 — 256 VGPRs.)
+constexpr int kWideCK = 8, kWideK = 7, kWidePad = 3;
+template <int PRO, int BT>
+__global__ __launch_bounds__(BT) void conv_cout1_wide_kernel(const ConvArgs p) {
+  constexpr int kWideBT = BT, kWideOut = 4 * BT, kWideW = kWideOut + 16;
   __shared__ __attribute__((aligned(16))) float xs[kWideCK * kWideW];
   __shared__ __attribute__((aligned(16))) float ws[256 * 8];  // [Cin ≤ 256][8]: 7 taps + a zero
   constexpr bool AVG = PRO == PRO_AVG3_LRELU;
@@ -217,11 +221,11 @@ __global__ __launch_bounds__(kWideBT) void conv_cout1_wide_kernel(const ConvArgs
   const float* x2b = AVG ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
   const float* x3b = AVG ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
   for (int i = tid; i < p.Cin * 8; i += kWideBT) ws[i] = (i & 7) < kWideK ? p.w[(i >> 3) * kWideK + (i & 7)] : 0.0f;
-  constexpr int kRows4 = kWideW / 4;   // 260 float4 per row: 256 by the thread's own column, 4 more by threads 0..31 (row = tid >> 2)
+  // BT + 4 float4 per row: BT by the thread's own column, 4 more by threads 0..31 (row = tid >> 2)
   float4 t[kWideCK + 1], t2[AVG ? kWideCK + 1 : 1], t3[AVG ? kWideCK + 1 : 1];
   auto slot = [&](int q, int& row, int& i4) {  // staging slot q of this thread → (row, float4 column); row ≥ kWideCK: none
     row = q < kWideCK ? q : (tid < 32 ? (tid >> 2) : kWideCK);
-    i4 = q < kWideCK ? tid : 256 + (tid & 3);
+    i4 = q < kWideCK ? tid : BT + (tid & 3);
   };
   auto issue = [&](int c0) {
 #pragma unroll
@@ -278,6 +282,16 @@ __global__ __launch_bounds__(kWideBT) void conv_cout1_wide_kernel(const ConvArgs
   for (int o = 0; o < 4; o++) {
     const int xo = t0 + 4 * tid + o;
     if (xo < p.Lout) store_elem(p, n, 0, xo, acc[o]);
+  }
+}
+
+template <int BT>
+void launch_wide(hipStream_t s, const ConvArgs& a) {
+  const dim3 g((unsigned)ceil_div(a.Lout, 4 * BT), (unsigned)a.N);
+  switch (a.prologue) {
+    case PRO_NONE: hipLaunchKernelGGL((conv_cout1_wide_kernel<PRO_NONE, BT>), g, dim3(BT), 0, s, a); break;
+    case PRO_LRELU: hipLaunchKernelGGL((conv_cout1_wide_kernel<PRO_LRELU, BT>), g, dim3(BT), 0, s, a); break;
+    default: hipLaunchKernelGGL((conv_cout1_wide_kernel<PRO_AVG3_LRELU, BT>), g, dim3(BT), 0, s, a); break;
   }
 }
 
@@ -372,6 +386,13 @@ bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups) {
   return stride == 1 && groups == 1 && Cout >= 8 && Cin >= 2 && k_supported(K);
 }
 
+// 16-wide tiles below this many 32-wide tiles (PIPER_HIP_TM16_BELOW: tuning experiments; r2 sweep: 0 … 128 cost +0.06 … +0.41 ms
+// on the factor-8 utterance, 512 and 1024 change nothing)
+static int64_t tile16_limit(piper_hip_ctx* ctx) {
+  static const int below = [] { const char* e = getenv("PIPER_HIP_TM16_BELOW"); return e ? atoi(e) : -1; }();
+  return below >= 0 ? below : ctx->num_cus;
+}
+
 int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   ConvArgs a = a_in;
   a.ct_shift = -1;
@@ -398,7 +419,7 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   {
     const int64_t tiles32 = (a.gate ? ceil_div(a.Cout, 64) : ceil_div(a.Cout, 32)) * ceil_div(a.Lout, 32) * a.N;
     static const int force_tm = [] { const char* e = getenv("PIPER_HIP_TM"); return e ? atoi(e) : 0; }();  // tuning experiments
-    if (a.w16 && (tiles32 < ctx->num_cus || force_tm == 16) && (!a.gate || a.Cout % 32 == 0)) TM = 16;
+    if (a.w16 && force_tm != 32 && (tiles32 < tile16_limit(ctx) || force_tm == 16) && (!a.gate || a.Cout % 32 == 0)) TM = 16;
   }
   if (TM == 16) a.w = a.w16;
   if (!a.w) PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: missing packed weights for %d-wide tiles", TM);
@@ -462,7 +483,7 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
 
 int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate) {
   const int64_t tiles32 = (gate ? ceil_div(Cout, 64) : ceil_div(Cout, 32)) * ceil_div(Lout, 32) * N;
-  return (tiles32 < ctx->num_cus && (!gate || Cout % 32 == 0)) ? 16 : 32;
+  return (tiles32 < tile16_limit(ctx) && (!gate || Cout % 32 == 0)) ? 16 : 32;
 }
 
 int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
@@ -472,17 +493,14 @@ int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
     PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "direct conv does not implement epilogue %d", a.epilogue);
   const int halo = (a.K - 1) * (a.dil < 0 ? -a.dil : a.dil);
   static const bool no_wide = getenv("PIPER_HIP_NO_WIDE_POST") != nullptr;
+  static const int wide_min = [] { const char* e = getenv("PIPER_HIP_WIDE_POST_MIN"); return e ? atoi(e) : 4096; }();  // shorter rows: small-Cout kernel
   if (!no_wide && a.Cout == 1 && a.K == kWideK && a.dil == 1 && a.padL == kWidePad && a.stride == 1 && a.groups == 1 && a.Lin == a.Lout && a.Cin <= 256 &&
       a.N <= 65535 && a.in_ch_sign > 0 && a.in_ch_base == 0 && a.out_ch_sign > 0 && a.out_ch_base == 0 && (a.Lin & 3) == 0 && (a.x_batch_stride & 3) == 0 &&
-      ((uintptr_t)a.x & 15) == 0 && a.Lin >= 64 * kWideOut &&
+      ((uintptr_t)a.x & 15) == 0 && a.Lin >= wide_min &&
       (a.prologue != PRO_AVG3_LRELU || ((((uintptr_t)a.x2 | (uintptr_t)a.x3) & 15) == 0)) &&
       (a.epilogue == EPI_STORE || a.epilogue == EPI_TANH) && !a.res && !a.gate) {
-    const dim3 g((unsigned)ceil_div(a.Lout, kWideOut), (unsigned)a.N);
-    switch (a.prologue) {
-      case PRO_NONE: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_NONE>, g, dim3(kWideBT), 0, s, a); break;
-      case PRO_LRELU: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_LRELU>, g, dim3(kWideBT), 0, s, a); break;
-      default: hipLaunchKernelGGL(conv_cout1_wide_kernel<PRO_AVG3_LRELU>, g, dim3(kWideBT), 0, s, a); break;
-    }
+    if (ceil_div(a.Lout, 1024) * a.N < 2 * ctx->num_cus) launch_wide<64>(s, a);
+    else launch_wide<256>(s, a);
     hipError_t e3 = hipGetLastError();
     if (e3 != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_cout1_wide launch failed: %s", hipGetErrorString(e3));
     return PIPER_HIP_OK;
