@@ -386,7 +386,7 @@ int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* 
   for (int pass = 0; pass < 3 && best < 0; pass++)  // 0: forced, 1: wanted KS, 2: anything that fits
     for (int i = 0; i < 6 && best < 0; i++) {
       const int m = cand[i][0], nn = cand[i][1], k = cand[i][2];
-      if (g.per_phase % m || (k > 1 && Sp_min / k < 16) || lds_bytes(a.Cin, nn, reach, k, m * nn) > 160 * 1024) continue;
+      if (g.MT % m || (k > 1 && Sp_min / k < 16) || lds_bytes(a.Cin, nn, reach, k, m * nn) > 160 * 1024) continue;
       if (pass == 0 && !(forced && m == fm && nn == fn && k == fk)) continue;
       if (pass == 1 && k != KS) continue;
       best = i;
