@@ -467,7 +467,7 @@ int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, piper_hip_k
                             int* n_entries);
 
 /* Time a subset of the slot's schedule the way it runs in production: the launches whose name contains `name_filter`
- * ("" = all) are captured into their own HIP graph and replayed `iters` times between two hipEvents on the slot's
+ * ("" = all; "a|b|c" = the launches named exactly a, b or c) are captured into their own HIP graph and replayed `iters` times between two hipEvents on the slot's
  * stream. avg_launch_us = elapsed / (iters · n_launches) — kernel time plus the dispatch boundary, no per-kernel event
  * overhead; flops/bytes are the algorithmic totals of the subset (SURVEY.md Appendix A recipe). */
 int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const char* name_filter, int iters, double* avg_launch_us,

@@ -436,7 +436,8 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   while (NT > 1 && waves(NT) < 2 * want) NT >>= 1;
   {
     static const int force_nt = [] { const char* e = getenv("PIPER_HIP_NT"); return e ? atoi(e) : 0; }();  // tuning experiments
-    if (force_nt > 0 && TM == 32 && a.Lout >= 4096) NT = force_nt;
+    static const int force_nt_min = [] { const char* e = getenv("PIPER_HIP_NT_MIN_L"); return e ? atoi(e) : 4096; }();
+    if (force_nt > 0 && TM == 32 && a.Lout >= force_nt_min) NT = force_nt;
   }
   if ((a.gate || a.prologue == PRO_AVG3_LRELU) && NT > 2) NT = 2;  // register budget: 2 accumulator sets / 3 raw inputs
   if (a.K >= 11 && NT > 2) NT = 2;
@@ -444,7 +445,8 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   // groups: short utterances have tiny outputs and long contractions, so this is their only parallelism.
   int ks_log2 = 0;
   const int ks_cap = (a.gate && TM == 32) ? 3 : 4;  // the gated 32-wide tile holds two 16-register accumulator sets
-  while (ks_log2 < ks_cap && waves(NT) * (1 << ks_log2) < want && ngroups / (2 << ks_log2) >= 2 && NT == 1) ks_log2++;
+  static const bool ks_any_nt = getenv("PIPER_HIP_KS_ANY_NT") != nullptr;  // tuning experiments: K-split also with NT > 1 (≤ 4 slices: BT 256)
+  while (ks_log2 < (NT == 1 ? ks_cap : 2) && waves(NT) * (1 << ks_log2) < want && ngroups / (2 << ks_log2) >= 2 && (NT == 1 || ks_any_nt)) ks_log2++;
   const int KS = 1 << ks_log2;
   const int BT = KS <= 4 ? 256 : 64 * KS;
   const int WT = (BT / 64) / KS;

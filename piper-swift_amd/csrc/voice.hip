@@ -2464,9 +2464,25 @@ PH_EXPORT int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const ch
   Slot& s = *sp;
   std::vector<int> pick;
   double fl = 0, by = 0;
+  // "a|b|c": the launches with exactly these names (one replayed graph for a whole kernel family); otherwise substring / tag match
+  std::vector<std::string> exact;
+  if (strchr(name_filter, '|')) {
+    std::string f(name_filter);
+    size_t b = 0;
+    while (b <= f.size()) {
+      const size_t e = f.find('|', b);
+      const std::string part = f.substr(b, e == std::string::npos ? std::string::npos : e - b);
+      if (!part.empty()) exact.push_back(part);
+      if (e == std::string::npos) break;
+      b = e + 1;
+    }
+  }
+  auto wanted = [&](const Step& st) {
+    if (!exact.empty()) return std::find(exact.begin(), exact.end(), st.name) != exact.end();
+    return st.name.find(name_filter) != std::string::npos || (!st.tag.empty() && st.tag == name_filter);
+  };
   for (int i = 0; i < (int)s.steps.size(); i++)
-    if (s.steps[i].kind == Step::LAUNCH &&
-        (s.steps[i].name.find(name_filter) != std::string::npos || (!s.steps[i].tag.empty() && s.steps[i].tag == name_filter))) {
+    if (s.steps[i].kind == Step::LAUNCH && wanted(s.steps[i])) {
       pick.push_back(i);
       fl += s.steps[i].flops;
       by += s.steps[i].bytes;
