@@ -239,6 +239,12 @@ def test_time_subset_and_profile(rt_medium):
     assert n_all > n and fl_all >= fl
     st = rt_medium.profile(10, iters=2)
     assert any(s["name"].startswith("(event floor") for s in st) and sum(s["flops"] for s in st) == pytest.approx(fl_all)
+    # "a|b|": exactly the named launches, replayed as one graph (how bench.py times a kernel family)
+    gates = [s["name"] for s in st if s["name"].endswith(".in_gate")]
+    assert len(gates) == 16
+    us_g, n_g, fl_g, _ = rt_medium.time_subset(10, "|".join(gates) + "|", iters=3)
+    assert n_g == 16 and us_g > 0 and fl_g == pytest.approx(sum(s["flops"] for s in st if s["name"] in gates))
+    assert rt_medium.time_subset(10, "no such launch|", iters=1)[1] == 0
     # profiling replays non-idempotent steps; a normal launch afterwards must still be exact
     rt_medium.launch(10)
     assert np.array_equal(ref, rt_medium.collect(10))
