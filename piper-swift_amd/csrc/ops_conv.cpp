@@ -116,8 +116,11 @@ PH_EXPORT int piper_hip_convtranspose1d_f32(piper_hip_ctx* ctx, const float* x, 
   static const bool no_win = getenv("PIPER_HIP_NO_WIN") != nullptr;
   if (!no_win && g == 1 && p->dilation == 1 && p->output_padding == 0 && p->pad_l == p->pad_r && Lin >= 256 &&
       ((uintptr_t)x & 15) == 0 && convt_win_eligible((int)Cin, (int)Cout, (int)K, s, p->pad_l, (int)Lin)) {
+    // the chunk-pipelined kernel only on request (PIPER_HIP_PIPE_CT_MIN_GFLOP): the window kernel is faster for ConvTranspose (voice.hip)
     static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
-    const bool pipe = !no_pipe && convt_pipe_eligible((int)Cin, (int)Cout, (int)K, s, p->pad_l, (int)Lin);
+    static const double pipe_ct_min = [] { const char* e = getenv("PIPER_HIP_PIPE_CT_MIN_GFLOP"); return e ? atof(e) * 1e9 : 1e30; }();
+    const bool pipe = !no_pipe && 2.0 * (double)Cout * (double)Cin * (double)K * (double)Lin * (double)N >= pipe_ct_min &&
+                      convt_pipe_eligible((int)Cin, (int)Cout, (int)K, s, p->pad_l, (int)Lin);
     float* packed = nullptr;
     rc = pool_floats(ctx, pipe ? packed_convt_pipe_floats((int)Cin, (int)Cout, (int)K, s) : packed_convt_win_floats((int)Cin, (int)Cout, (int)K, s), &packed);
     if (rc) return rc;

@@ -872,9 +872,13 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
   static const bool no_pipe = getenv("PIPER_HIP_NO_PIPE") != nullptr;
   static const double pipe_min_flops = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
   // r2f (factor 64): as a single-conv launch it also loses at 32 / 64 channels (135 vs 114 µs, 105 vs 100 µs: one chunk per
-  // tile leaves nothing to pipeline, and 2 blocks per CU hide less than the window kernel's 4) and wins for ConvTranspose
-  // (112 vs 145 µs, 133 vs 142 µs) and from 128 channels up.
-  auto pipe_pays = [&](double launch_flops, int Cin, bool ct) { return !no_pipe && launch_flops >= pipe_min_flops && (ct || Cin >= 128); };
+  // tile leaves nothing to pipeline, and 2 blocks per CU hide less than the window kernel's 4) and wins from 128 channels up.
+  // ConvTranspose: it won (112 vs 145 µs) until the window kernel staged narrow windows with a flat index and kept the phases
+  // of a column range in one block; since then the window kernel wins at every size measured (factor 64: 126 / 121 vs
+  // 187 / 204 µs, 8 × factor 8: 111 / 119 vs 181 / 201 µs, high voice factor 32: 215 vs 312 µs) — never by default,
+  // PIPER_HIP_PIPE_CT_MIN_GFLOP=g brings it back for launches of ≥ g GFLOP.
+  static const double pipe_ct_min_flops = [] { const char* e = getenv("PIPER_HIP_PIPE_CT_MIN_GFLOP"); return e ? atof(e) * 1e9 : 1e30; }();
+  auto pipe_pays = [&](double launch_flops, int Cin, bool ct) { return !no_pipe && launch_flops >= (ct ? pipe_ct_min_flops : pipe_min_flops) && (ct || Cin >= 128); };
   {
     int L = F;
     for (int u = 0; u < c.n_ups; u++) {
@@ -1057,7 +1061,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   static const bool use_win = getenv("PIPER_HIP_NO_WIN") == nullptr;  // window kernel for the generator's long rows
   static const bool no_pipe1 = getenv("PIPER_HIP_NO_PIPE") != nullptr;
   static const double pipe_min_flops1 = [] { const char* e = getenv("PIPER_HIP_PIPE_MIN_GFLOP"); return (e ? atof(e) : 5.0) * 1e9; }();
-  auto pipe_pays1 = [&](double launch_flops, int Cin, bool ct) { return !no_pipe1 && launch_flops >= pipe_min_flops1 && (ct || Cin >= 128); };
+  static const double pipe_ct_min_flops1 = [] { const char* e = getenv("PIPER_HIP_PIPE_CT_MIN_GFLOP"); return e ? atof(e) * 1e9 : 1e30; }();
+  auto pipe_pays1 = [&](double launch_flops, int Cin, bool ct) { return !no_pipe1 && launch_flops >= (ct ? pipe_ct_min_flops1 : pipe_min_flops1) && (ct || Cin >= 128); };
   Arena ar{v, &s};
   if (c.n_rb != 3) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice: n_rb=%d (only the 3-kernel MRF of Piper voices is scheduled)", c.n_rb);
   s.T = T; s.F = F; s.NB = NB;

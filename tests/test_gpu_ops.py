@@ -455,6 +455,25 @@ def test_convtranspose1d_long_rows_window_kernel(idx, backend):
     assert_close(dl(backend, out, shp), ref, OP_TOL, f"convT window case {idx}")
 
 
+def test_convtranspose1d_chunk_pipelined_kernel_on_request():
+    """conv_pipe_kernel's ConvTranspose path is off by default (the window kernel is faster since round 2) and selected by
+    PIPER_HIP_PIPE_CT_MIN_GFLOP; the switch is read once per process, so the cases run in a child process with it set."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "probe", "convt_pipe_check.py")
+    env = dict(os.environ, PIPER_HIP_PIPE_CT_MIN_GFLOP="0")
+    env.pop("PIPER_HIP_NO_PIPE", None)
+    out = subprocess.run([sys.executable, tool, "0", "4", "5"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = re.findall(r"case (\d+): max_abs_err ([0-9.e+-]+) ref_max ([0-9.e+-]+)", out.stdout)
+    assert [int(r[0]) for r in rows] == [0, 4, 5], out.stdout
+    for _, err, ref_max in rows:
+        assert float(err) <= OP_TOL * max(1.0, float(ref_max)), out.stdout
+
+
 def test_comm_single_rank_world(backend):
     """piper_hip_comm_* over rccl.h with a world of one (all a one-GPU box can hold): the communicator reports its own size,
     the in-place broadcast leaves the root's data untouched, MAX of one value is that value, barrier returns."""
