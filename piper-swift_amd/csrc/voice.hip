@@ -2165,6 +2165,20 @@ PH_EXPORT int piper_hip_voice_plan_info(const piper_hip_voice* v, int slot, int3
   return PIPER_HIP_OK;
 }
 
+namespace {
+// waveform → page-locked host memory through its device mapping (collect): 16-byte stores where both sides allow, grid-stride
+__global__ __launch_bounds__(256) void copy_out_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) ((float4*)dst)[i] = ((const float4*)src)[i];
+    for (int64_t i = (n4 << 2) + tid; i < n; i += nth) dst[i] = src[i];
+  } else {
+    for (int64_t i = tid; i < n; i += nth) dst[i] = src[i];
+  }
+}
+}  // namespace
+
 PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
   Slot* p = slot_plan(v, slot);
@@ -2208,11 +2222,25 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
       else { s.h_audio = nullptr; (void)hipGetLastError(); }
     }
     float* dst = (!caller_pinned && bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
+    // Short waveforms into page-locked memory are written by a KERNEL through the host mapping instead of the copy engine: the
+    // hand-over from the last kernel of the graph to another kernel costs ≈ 2 µs, to the DMA engine ≈ 10 µs (PIPER_HIP_COLLECT_DMA=1:
+    // always the copy engine).
+    static const bool dma_only = getenv("PIPER_HIP_COLLECT_DMA") != nullptr;
+    float* dst_dev = nullptr;
+    if (!dma_only && bytes <= kPinnedMax && (caller_pinned || dst == s.h_audio)) {
+      if (hipHostGetDevicePointer((void**)&dst_dev, dst, 0) != hipSuccess) { dst_dev = nullptr; (void)hipGetLastError(); }
+    }
     int64_t off = 0;
     for (int b = 0; b < s.NB; b++) {
       const int64_t nb = (int64_t)s.h_F[b] * v->hop;
-      PH_HIP(hipMemcpyAsync(dst + off, s.audio + (int64_t)b * s.n_samples, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, s.stream),
-             PIPER_HIP_ERR_LAUNCH);
+      const float* src = s.audio + (int64_t)b * s.n_samples;
+      if (dst_dev && nb > 0) {
+        const int blocks = (int)std::min<int64_t>((nb + 4 * 256 - 1) / (4 * 256), 1024);
+        hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, s.stream, src, dst_dev + off, nb);
+        PH_HIP(hipGetLastError(), PIPER_HIP_ERR_LAUNCH);
+      } else {
+        PH_HIP(hipMemcpyAsync(dst + off, src, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
+      }
       off += nb;
     }
     PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
