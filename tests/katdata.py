@@ -230,4 +230,6 @@ CONVT_WIN_CASES = [
     (128, 64, 4, 2, 260, 1),
     (64, 32, 8, 4, 60000, 1),   # conv_pipe: 4 row tiles (one per phase) × 1 875 column tiles: several tiles per block
     (32, 32, 4, 2, 9000, 2),    # one chunk per tile, 2 phases × 32 rows, batch 2
+    (64, 96, 4, 2, 5000, 1),    # 6 row tiles (3 per phase) in row groups of 2: the middle group spans both phases
+    (32, 64, 6, 3, 2052, 2),    # stride 3 (shift-free phase index), 6 row tiles, L % 32 != 0, batch 2
 ]
