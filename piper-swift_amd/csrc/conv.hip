@@ -428,8 +428,10 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   const int mt_eff = a.gate ? mtiles / 2 : mtiles;
   const int G = group_of(a.K);
   const int ngroups = (int)ceil_div((a.Cin + cps - 1) / cps, G);
-  // tile shape: give every SIMD (4 per CU) a wave before growing the per-wave tile
-  const int64_t want = (int64_t)ctx->num_cus * 4;
+  // tile shape: give every SIMD (4 per CU) two waves before growing the per-wave tile (one wave per SIMD until round 2's sweeps)
+  static const int want_mul = [] { const char* e = getenv("PIPER_HIP_KS_WANT_MUL"); return e ? atoi(e) : 2; }();  // r2 sweep: 1 / 2 / 4 → 0.881 / 0.854 / 0.859 ms at factor 8
+  static const int want_mul32 = [] { const char* e = getenv("PIPER_HIP_KS_WANT_MUL32"); return e ? atoi(e) : 2; }();  // 8 × factor 8: 3.30 → 3.18 ms, factor 64 −1 %, else neutral
+  const int64_t want = (int64_t)ctx->num_cus * 4 * (TM == 16 ? want_mul : want_mul32);
   int NT = TM == 32 ? 4 : 1;
   // grow the per-wave tile only while every SIMD still gets ≥ 2 waves (a second wave is what hides load latency)
   auto waves = [&](int nt) { return (int64_t)mt_eff * ceil_div(a.Lout, TM * nt) * a.N; };

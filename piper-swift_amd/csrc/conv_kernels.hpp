@@ -181,10 +181,13 @@ __device__ __forceinline__ int bias_index(const ConvArgs& p, int row) {
   return p.ct_shift >= 0 ? (row >> p.ct_shift) : (row / p.ct_stride);
 }
 
-// Contraction steps fetched per prefetch group = G(K) channel pairs × K taps (≈ 7–11 steps)
+// Contraction steps fetched per prefetch group = G(K) channel units × K taps. Small groups on purpose (2–7 steps): the in-block
+// K-split keeps ≥ 2 groups per slice, so the group size caps how finely a short-utterance conv can be spread over waves and
+// blocks — and that, not the depth of the prefetch, is what these launches are bound by (DESIGN.md finding 10). r2: G(1) 8 → 4 → 2
+// took the factor-8 utterance 0.905 → 0.877 → 0.870 ms (factor 1: 0.703 → 0.676 → 0.650), G(1) = 1 gave some of it back.
 template <int K>
 struct GroupOf {
-  static constexpr int G = K == 1 ? 8 : K == 2 ? 4 : K == 3 ? 3 : K == 5 ? 2 : 1;
+  static constexpr int G = K == 1 ? 2 : K == 2 ? 4 : K == 3 ? 2 : K == 5 ? 1 : 1;
 };
 
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvArgs p, const 
 }
 
 inline bool k_supported(int K) { return K == 1 || K == 2 || K == 3 || K == 5 || K == 7 || K == 11; }
-inline int group_of(int K) { return K == 1 ? 8 : K == 2 ? 4 : K == 3 ? 3 : K == 5 ? 2 : 1; }
+inline int group_of(int K) { return K == 1 ? 2 : K == 2 ? 4 : K == 3 ? 2 : K == 5 ? 1 : 1; }
 inline int padded_steps(int Cin, int K, int tm = 32) {
   const int cps = tm == 32 ? 2 : 4;
   const int ncu = (Cin + cps - 1) / cps, G = group_of(K);
