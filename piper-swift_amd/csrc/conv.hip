@@ -386,11 +386,13 @@ bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups) {
   return stride == 1 && groups == 1 && Cout >= 8 && Cin >= 2 && k_supported(K);
 }
 
-// 16-wide tiles below this many 32-wide tiles (PIPER_HIP_TM16_BELOW: tuning experiments; r2 sweep: 0 … 128 cost +0.06 … +0.41 ms
-// on the factor-8 utterance, 512 and 1024 change nothing)
+// 16-wide tiles below this many 32-wide tiles (PIPER_HIP_TM16_BELOW). Round 1 used them only when 32-wide tiles could not give
+// every CU one; the r2 sweeps say four times as many, smaller tiles win far beyond that: 0 … 128 cost +0.06 … +0.41 ms on the
+// factor-8 utterance; 256 → 1024 → 2048 take 4 × factor 8 from 2.10 to 1.85 ms, 8 × factor 8 from 3.14 to 2.91, factor 64
+// from 3.17 to 3.10; above 2048 (up to "always") nothing changes.
 static int64_t tile16_limit(piper_hip_ctx* ctx) {
   static const int below = [] { const char* e = getenv("PIPER_HIP_TM16_BELOW"); return e ? atoi(e) : -1; }();
-  return below >= 0 ? below : ctx->num_cus;
+  return below >= 0 ? below : 8 * (int64_t)ctx->num_cus;
 }
 
 int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
