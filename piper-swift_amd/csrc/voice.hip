@@ -1133,8 +1133,12 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   // LayerNorms without launches of their own: the conv BEFORE a LayerNorm adds the residual and leaves per-column partial
   // sums (stats_out), the conv AFTER it normalises its input on load (PRO_LN) and writes the normalised tensor once.
   // PIPER_HIP_NO_LN_FUSE=1 keeps the add+LayerNorm kernels (A/B).
+  // Above ≈ 640 columns (r2: factor 64 and 8 × factor 8, T·NB = 896: 3.07–3.09 vs 3.10 ms, 2.87 vs 2.90 ms) the normalisation
+  // inside the consumers' K loops costs more than the twelve launches it saves; up to T·NB = 448 the fused form wins (factor 8:
+  // 0.853 vs 0.879 ms). PIPER_HIP_LN_FUSE_MAX_T moves the crossover.
   static const bool ln_fuse = getenv("PIPER_HIP_NO_LN_FUSE") == nullptr;
-  const bool ln_ok = ln_fuse && (kf == 1 || kf == 3) && v->proj.mfma && H <= 256;
+  static const int64_t ln_fuse_max_t = [] { const char* e = getenv("PIPER_HIP_LN_FUSE_MAX_T"); return e ? atoll(e) : 640ll; }();
+  const bool ln_ok = ln_fuse && (kf == 1 || kf == 3) && v->proj.mfma && H <= 256 && (int64_t)T * NB <= ln_fuse_max_t;
   float* st1 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   float* st2 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   if (ar.rc) return ar.rc;
