@@ -13,6 +13,7 @@
 //      or 4 contiguous step ranges) and reduce in fixed order through LDS — deterministic, like conv_stream_kernel;
 //   4. epilogue: bias, residual, MRF mean, LeakyReLU, ConvTranspose scatter — loads first, masked stores after.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_win.h"
@@ -373,8 +374,10 @@ int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* 
   }
   const int64_t tiles = (int64_t)g.MT * ceil_div(a.Lout, 32) * a.N * count;
   const int64_t simds = 4 * (int64_t)ctx->num_cus;
-  // split the contraction while there are fewer tiles than SIMDs (each split wave keeps ≥ 16 steps)
-  int KS = tiles >= simds ? 1 : (2 * tiles >= simds ? 2 : 4);
+  // split the contraction while the tiles give a SIMD fewer than two waves (each split wave keeps ≥ 16 steps); one wave per SIMD
+  // was the target until the r2 sweeps (factor 8 stage-1 upsampler, 1344 tiles: 27.6 → 25.4 µs with the split)
+  static const bool ks_one_wave = getenv("PIPER_HIP_WIN_KS_ONE_WAVE") != nullptr;  // A/B: round 1's one-wave-per-SIMD target
+  int KS = ks_one_wave ? (tiles >= simds ? 1 : (2 * tiles >= simds ? 2 : 4)) : (tiles >= 2 * simds ? 1 : (tiles >= simds ? 2 : 4));
   while (KS > 1 && Sp_min / KS < 16) KS >>= 1;
   // candidates in order of preference: the wanted K-split first; waves along rows before columns (they then share the
   // staged window and nothing else); a single row tile (C = 32) puts the waves side by side along the columns
