@@ -14,6 +14,7 @@
 //      (ds_read_b128, conflict-free: 32 consecutive positions of one channel block) from the window, double-buffered;
 //   3. epilogue: bias, fp32 residual, MRF mean, fp32 store and/or the C8 bf16 image of LeakyReLU(result) for the next conv.
 #include <algorithm>
+#include <cstdlib>
 
 #include "conv_bf16.h"
 
@@ -416,7 +417,8 @@ int launch_conv_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args
   int NTW = 4;
   auto blocks = [&](int mtw, int ntw) { return ceil_div(MT, WM * mtw) * ceil_div(a.Lout, WN * ntw * 32) * a.N * count; };
   auto lds_bytes = [&](int wn, int ntw) { return (size_t)(a.Cin / 8) * (wn * ntw * 32 + reach) * 16 + 16; };
-  const int64_t want = 2 * (int64_t)ctx->num_cus;  // keep every CU busy before growing the per-wave tile
+  static const int want_blocks = [] { const char* e = getenv("PIPER_HIP_BF16_WANT_BLOCKS"); return e ? atoi(e) : 2; }();  // per CU (tuning)
+  const int64_t want = want_blocks * (int64_t)ctx->num_cus;  // keep every CU busy before growing the per-wave tile
   while (NTW > 1 && (blocks(MTW, NTW) < want || lds_bytes(WN, NTW) > 160 * 1024)) NTW >>= 1;
   if (MTW == 2 && blocks(MTW, NTW) < want) MTW = 1;
   if (const char* force = getenv("PIPER_HIP_BF16_CFG")) {  // tuning hook: "MTW,NTW,WM" (ignored when it does not divide the problem)
