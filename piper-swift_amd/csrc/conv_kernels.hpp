@@ -344,7 +344,7 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       // D = 2 above 256 threads. (A deeper ring there — so that a wave's 3–4 groups are all in flight before its first MFMA — was
       // measured: the flow's gated conv stayed at 13.4 µs, the FFN's second conv went 12.9 → 16.7 µs. These launches are bound by the
       // bytes their CU pulls in, not by dependent round trips. Re-measured with the small groups of round 2 (ring of 3–4 wherever ≤ 64–96
-      // registers allow): factor 8 0.849 → 0.884 ms, factor 1 0.648 → 0.675.)
+      // registers allow): factor 8 0.849 → 0.884 ms, factor 1 0.648 → 0.675. Capping the ring at 2 everywhere costs 8 % at factor 64, at 3 nothing.)
       constexpr int D = BT > 256 ? 2 : (regs_per_group * 4 <= 112 ? 4 : (regs_per_group * 3 <= 132 ? 3 : 2));
       float av[D][NA][S], bv[D][NX][S][NT];
       float lng[PRO == PRO_LN ? D : 1][G], lnb[PRO == PRO_LN ? D : 1][G];  // gamma / beta of this lane's channel per channel unit
