@@ -590,12 +590,18 @@ constexpr int kTK = 128;               // keys per staged tile
 constexpr int kLdK = kTK + 16;         // ≡ 16 (mod 32)
 constexpr int kLdV = kTK + 2;          // ≡ 2 (mod 32)
 
-template <int D>
+// SPLIT (long rows): blockIdx.y = head · nsplit + part; the block covers only the key tiles of its part, leaves the probabilities
+// unnormalised (e^{s − m} with the part's own row maximum m) and writes its share of P·V plus (m, Σ e) per query row to scratch;
+// rel_attention_merge_kernel combines the parts (out = Σ_p e^{m_p − M} o_p / Σ_p e^{m_p − M} l_p). A block's time is what its CU
+// pulls in — all of K and V of its head, 688 KB at T = 896, at ≈ 8 B/clk (DESIGN.md finding 9; two tiles in flight did not help) —
+// so halving the bytes per block is what shortens the launch.
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                           const float* __restrict__ v, const float* __restrict__ ek,
                                                                           const float* __restrict__ ev, float* __restrict__ out, int T,
                                                                           int w, int64_t in_batch_stride, int64_t out_batch_stride,
-                                                                          const int* __restrict__ len_ptr, int Tp) {
+                                                                          const int* __restrict__ len_ptr, int Tp, int nsplit,
+                                                                          float* __restrict__ part_o, float* __restrict__ part_ml) {
   constexpr int RV = 16, NS = D / 4, NCT = D / 16;
   constexpr int NT = 64 * kAttWaves;                 // threads
   constexpr int F4 = D * (kTK / 4);                  // float4 slots of a staged tile
@@ -608,7 +614,9 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
-  const int i0 = blockIdx.x * RV, h = blockIdx.y, n = blockIdx.z;
+  const int i0 = blockIdx.x * RV, n = blockIdx.z;
+  const int h = SPLIT ? (int)blockIdx.y / nsplit : (int)blockIdx.y;
+  const int part = SPLIT ? (int)blockIdx.y - h * nsplit : 0;
   const int Tv = len_ptr ? min(len_ptr[n], T) : T;
   if (i0 >= Tv) return;
   const int W = 2 * w + 1;
@@ -617,7 +625,15 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
   const float* kb = k + hoff;
   const float* vb = v + hoff;
   const float scale = sqrtf((float)D);
-  const int ntile = (Tv + kTK - 1) / kTK;
+  const int ntile_all = (Tv + kTK - 1) / kTK;
+  // this block's key tiles [tb, te) and keys [kbeg, kend): parts of ceil(ntile / nsplit) tiles (a part past the end is empty: the
+  // merge kernel applies the same rule and skips it)
+  const int tpp = SPLIT ? (ntile_all + nsplit - 1) / nsplit : ntile_all;
+  const int tb = SPLIT ? part * tpp : 0;
+  const int te = SPLIT ? min(tb + tpp, ntile_all) : ntile_all;
+  if (SPLIT && tb >= te) return;
+  const int kbeg = tb * kTK, kend = min(te * kTK, Tv);
+  const int ntile = te - tb;
 
   float4 stg[SLOTS];
   // tile `t0` of `src` → registers: slot e = tid + NT·i ↔ (row = e / 32, 16-byte column = e % 32); rows are T floats apart and
@@ -647,7 +663,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
   };
 
   // ---- 0. q strip → LDS (scaled: Div of the graph), first K tile in flight
-  fetch(kb, 0);
+  fetch(kb, kbeg);
   for (int e = tid; e < D * 16; e += NT) {
     const int c = e >> 4, i = e & 15;
     const bool ok = i0 + i < Tv;
@@ -661,7 +677,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
 #pragma unroll
     for (int s = 0; s < NS; s++) ekf[s] = ek[mc * D + 4 * s + kq];
   }
-  commit(kLdK, 0);
+  commit(kLdK, kbeg);
   __syncthreads();
   if (wave == kAttWaves - 1) {
     f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -676,9 +692,9 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
 
   // ---- 1. scores, one staged K tile (8 key tiles of 16, one per wave) at a time
   for (int t = 0; t < ntile; t++) {
-    const int t0 = t * kTK;
+    const int t0 = kbeg + t * kTK;
     if (t + 1 < ntile) fetch(kb, t0 + kTK);  // next K tile in flight
-    else fetch(vb, 0);                       // … or V's first tile: lands under the softmax
+    else fetch(vb, kbeg);                    // … or V's first tile: lands under the softmax
     const int j0 = t0 + wave * 16;
     if (j0 < Tv) {  // wave-uniform
       const bool col_ok = j0 + r16 < Tv;
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     float* row = sc + r * Tp;
     const float* qr = qe + r * 17;
     float m = -INFINITY;
-    for (int j = lane; j < Tv; j += 64) {
+    for (int j = kbeg + lane; j < kend; j += 64) {
       const int delta = j - ia;
       float sv = row[j];
       if (delta >= -w && delta <= w) sv += qr[delta + w];
@@ -715,16 +731,24 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     }
     m = wave_max(m);
     float sum = 0.0f;
-    for (int j = lane; j < Tv; j += 64) {
+    for (int j = kbeg + lane; j < kend; j += 64) {
       const float e = expf(row[j] - m);
       row[j] = e;
       sum += e;
     }
     sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    for (int j = lane; j < Tv; j += 64) row[j] *= inv;
+    if constexpr (SPLIT) {  // unnormalised: (m, Σ e) go to the merge
+      if (lane == 0) {
+        float* ml = part_ml + (((int64_t)n * gridDim.y + blockIdx.y) * 2) * T;
+        ml[ia] = m;
+        ml[T + ia] = sum;
+      }
+    } else {
+      const float inv = 1.0f / sum;
+      for (int j = lane; j < Tv; j += 64) row[j] *= inv;
+    }
   }
-  commit(kLdV, 0);
+  commit(kLdV, kbeg);
   __syncthreads();
 
   // ---- 3. P·V over the staged V tiles (waves 0 … NCT−1: one 16-channel tile each), then the relative-value steps
@@ -737,7 +761,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     for (int s = 0; s < 4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + wave * 16 + r16];
   }
   for (int t = 0; t < ntile; t++) {
-    const int t0 = t * kTK;
+    const int t0 = kbeg + t * kTK;
     if (t + 1 < ntile) fetch(vb, t0 + kTK);
     if (wave < NCT) {
       const float* vrow = tile + (wave * 16 + r16) * kLdV;
@@ -764,11 +788,11 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
       const int mrel = 4 * s + kq;
       const bool mok = mrel < W;
       const int j = ia + mrel - w;
-      const bool jok = mok && pi_ok && j >= 0 && j < Tv;
-      const float b = prow[jok ? j : 0];
+      const bool jok = mok && pi_ok && j >= kbeg && j < kend;
+      const float b = prow[jok ? j : kbeg];
       if (4 * s < W) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mok ? arel[s] : 0.0f, jok ? b : 0.0f, acc, 0, 0, 0);
     }
-    float* ob = out + (int64_t)n * out_batch_stride + (int64_t)h * D * T;
+    float* ob = SPLIT ? part_o + ((int64_t)n * gridDim.y + blockIdx.y) * D * T : out + (int64_t)n * out_batch_stride + (int64_t)h * D * T;
     if (pi_ok) {
 #pragma unroll
       for (int r = 0; r < 4; r++) ob[(int64_t)(wave * 16 + 4 * kq + r) * T + i0 + r16] = acc[r] + accb[r];
@@ -776,17 +800,56 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
   }
 }
 
+// out[n][h·D + c][i] = Σ_p e^{m_p − M} o_p[c][i] / Σ_p e^{m_p − M} l_p over the parts that hold keys (the kernel's own rule)
+template <int D>
+__global__ __launch_bounds__(256) void rel_attention_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                  float* __restrict__ out, int H, int T, int nsplit, int64_t out_batch_stride,
+                                                                  const int* __restrict__ len_ptr) {
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int Tv = len_ptr ? min(len_ptr[n], T) : T;
+  const int ntile_all = (Tv + kTK - 1) / kTK;
+  const int tpp = (ntile_all + nsplit - 1) / nsplit;
+  const int live = min(nsplit, (ntile_all + tpp - 1) / tpp);  // parts with at least one key tile
+  const int64_t pbase = ((int64_t)n * H + h) * nsplit;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < D * T; e += gridDim.x * 256) {
+    const int c = e / T, i = e - c * T;
+    if (i >= Tv) continue;
+    float M = -INFINITY;
+    for (int p = 0; p < live; p++) M = fmaxf(M, part_ml[(pbase + p) * 2 * T + i]);
+    float num = 0.0f, den = 0.0f;
+    for (int p = 0; p < live; p++) {
+      const float sc = expf(part_ml[(pbase + p) * 2 * T + i] - M);
+      num = fmaf(sc, part_o[(pbase + p) * D * T + (int64_t)c * T + i], num);
+      den = fmaf(sc, part_ml[(pbase + p) * 2 * T + T + i], den);
+    }
+    out[(int64_t)n * out_batch_stride + ((int64_t)h * D + c) * T + i] = num / den;
+  }
+}
+
 template <int D>
 int launch_att_lds(hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, float* out, int N, int H,
-                   int T, int w, int64_t in_bs, int64_t out_bs, const int* len_ptr) {
+                   int T, int w, int64_t in_bs, int64_t out_bs, const int* len_ptr, int nsplit, float* part_o, float* part_ml) {
   const int Tp = ((T + 31) / 32) * 32 + 2;
   const size_t lds = ((size_t)D * kLdK + (size_t)16 * Tp + (size_t)D * 16 + 16 * 17) * sizeof(float);
   if (lds > 160 * 1024) return -1;
   static bool raised[ph::kMaxDevices] = {};
+  static bool raised_split[ph::kMaxDevices] = {};
+  if (nsplit > 1) {
+    if (H * nsplit > 65535) return -1;
+    if (lds > 64 * 1024 && ph::lds_optin_needed(raised_split))
+      (void)hipFuncSetAttribute((const void*)rel_attention_lds_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    dim3 grid((unsigned)ph::ceil_div(T, 16), (unsigned)(H * nsplit), (unsigned)N);
+    hipLaunchKernelGGL((rel_attention_lds_kernel<D, true>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp,
+                       nsplit, part_o, part_ml);
+    dim3 mgrid((unsigned)std::min<int64_t>(ph::ceil_div((int64_t)D * T, 256), 64), (unsigned)H, (unsigned)N);
+    hipLaunchKernelGGL((rel_attention_merge_kernel<D>), mgrid, dim3(256), 0, s, part_o, part_ml, out, H, T, nsplit, out_bs, len_ptr);
+    return 0;
+  }
   if (lds > 64 * 1024 && ph::lds_optin_needed(raised))
-    (void)hipFuncSetAttribute((const void*)rel_attention_lds_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)rel_attention_lds_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   dim3 grid((unsigned)ph::ceil_div(T, 16), (unsigned)H, (unsigned)N);
-  hipLaunchKernelGGL((rel_attention_lds_kernel<D>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp);
+  hipLaunchKernelGGL((rel_attention_lds_kernel<D, false>), grid, dim3(64 * kAttWaves), lds, s, q, k, v, ek, ev, out, T, w, in_bs, out_bs, len_ptr, Tp,
+                     1, nullptr, nullptr);
   return 0;
 }
 
@@ -809,6 +872,37 @@ int launch_att_block(hipStream_t s, const float* q, const float* k, const float*
 }  // namespace
 
 namespace ph {
+int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek, const float* ev, float* out,
+                         int N, int H, int d, int T, int w, int64_t in_batch_stride, int64_t out_batch_stride, const int* len_ptr);
+
+// Key-split form: as many parts as keep the grid within one block per CU (more only queue up behind each other — r2 at T = 896:
+// 2 parts 40 µs, 3 parts 46, 4 parts 48, unsplit 48; at T = 560: 32 / 29 / 29, unsplit 35; T = 336: 25 → 20, T = 224: 19.6 → 18.6), at
+// most one part per key tile (so nothing changes up to T = 128). part_o: N·H·parts·d·T floats, part_ml: N·H·parts·2·T floats of scratch.
+int rel_attention_split_parts(piper_hip_ctx* ctx, int N, int H, int d, int T, int w) {
+  static const bool no_split = getenv("PIPER_HIP_ATT_NO_SPLIT") != nullptr;
+  static const int forced = [] { const char* e = getenv("PIPER_HIP_ATT_SPLIT"); return e ? std::min(std::max(atoi(e), 2), 8) : 0; }();  // tuning
+  static const int min_t = [] { const char* e = getenv("PIPER_HIP_ATT_SPLIT_MIN_T"); return e ? atoi(e) : 129; }();  // two key tiles or more
+  if (no_split || d != 96 || T < min_t || T > 1024 || (T & 3) != 0 || w < 0 || 2 * w + 1 > 16 || N < 1 || H < 1) return 1;
+  const int ntile = (T + kTK - 1) / kTK;
+  const int64_t blocks = (int64_t)ceil_div(T, 16) * H * N;
+  const int parts = forced ? forced : (int)std::min<int64_t>(ntile, ctx->num_cus / std::max<int64_t>(1, blocks));
+  return std::max(1, std::min(parts, 8));
+}
+
+int launch_rel_attention_split(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
+                               const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
+                               int64_t out_batch_stride, const int* len_ptr, int nsplit, float* part_o, float* part_ml) {
+  if (N <= 0 || T <= 0) return PIPER_HIP_OK;
+  if (nsplit < 2 || !part_o || !part_ml || d != 96 || H > 65535 || N > 65535 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) != 0 ||
+      (in_batch_stride & 3) != 0 || nsplit > (T + kTK - 1) / kTK || nsplit > 8 || T > 1024 || (T & 3) != 0 || w < 0 || 2 * w + 1 > 16)
+    return launch_rel_attention(ctx, s, q, k, v, ek, ev, out, N, H, d, T, w, in_batch_stride, out_batch_stride, len_ptr);
+  if (launch_att_lds<96>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr, nsplit, part_o, part_ml) != 0)
+    return launch_rel_attention(ctx, s, q, k, v, ek, ev, out, N, H, d, T, w, in_batch_stride, out_batch_stride, len_ptr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention (split) launch failed: %s", hipGetErrorString(e));
+  return PIPER_HIP_OK;
+}
+
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
                          int64_t out_batch_stride, const int* len_ptr) {
@@ -817,7 +911,7 @@ int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, cons
   static const bool no_lds = getenv("PIPER_HIP_ATT_NO_LDS") != nullptr;  // A/B switch: register-fragment MFMA kernel
   if (!no_mfma && !no_lds && d == 96 && w >= 0 && 2 * w + 1 <= 16 && H <= 65535 && N <= 65535 && T <= 1024 && T >= 4 && (T & 3) == 0 &&
       (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0 && (in_batch_stride & 3) == 0) {
-    if (launch_att_lds<96>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr) == 0) {
+    if (launch_att_lds<96>(s, q, k, v, ek, ev, out, N, H, T, w, in_batch_stride, out_batch_stride, len_ptr, 1, nullptr, nullptr) == 0) {
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "rel_attention (lds) launch failed: %s", hipGetErrorString(e));
       return PIPER_HIP_OK;
@@ -917,8 +1011,20 @@ PH_EXPORT int piper_hip_rel_attention_f32(piper_hip_ctx* ctx, const float* q, co
   if (!q || !k || !v || !emb_rel_k || !emb_rel_v) PH_FAIL(PIPER_HIP_ERR_ARG, "rel_attention: null input");
   ph::StreamScope ss(ctx, stream);
   const int64_t bs = heads * head_dim * t;
-  rc = ph::launch_rel_attention(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, *out, (int)n, (int)heads, (int)head_dim, (int)t,
-                                (int)window, bs, bs, nullptr);
+  const int nsplit = ph::rel_attention_split_parts(ctx, (int)n, (int)heads, (int)head_dim, (int)t, (int)window);
+  if (nsplit > 1) {
+    void *po = nullptr, *pml = nullptr;
+    rc = ctx->pool.alloc((size_t)(n * heads * nsplit * head_dim * t) * sizeof(float), &po);
+    if (rc) return rc;
+    ph::defer_free(ctx, po);
+    rc = ctx->pool.alloc((size_t)(n * heads * nsplit * 2 * t) * sizeof(float), &pml);
+    if (rc) return rc;
+    ph::defer_free(ctx, pml);
+    rc = ph::launch_rel_attention_split(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, *out, (int)n, (int)heads, (int)head_dim, (int)t, (int)window, bs,
+                                        bs, nullptr, nsplit, (float*)po, (float*)pml);
+  } else
+    rc = ph::launch_rel_attention(ctx, ss.s, q, k, v, emb_rel_k, emb_rel_v, *out, (int)n, (int)heads, (int)head_dim, (int)t,
+                                  (int)window, bs, bs, nullptr);
   if (rc) return rc;
   return ss.finish("rel_attention_f32");
 }

@@ -29,6 +29,10 @@ int validate_config(const piper_hip_voice_config* c);
 int launch_rel_attention(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
                          const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
                          int64_t out_batch_stride, const int* len_ptr);
+int rel_attention_split_parts(piper_hip_ctx* ctx, int N, int H, int d, int T, int w);
+int launch_rel_attention_split(piper_hip_ctx* ctx, hipStream_t s, const float* q, const float* k, const float* v, const float* ek,
+                               const float* ev, float* out, int N, int H, int d, int T, int w, int64_t in_batch_stride,
+                               int64_t out_batch_stride, const int* len_ptr, int nsplit, float* part_o, float* part_ml);
 size_t dp_scalars_bytes(int n);
 void dp_scalars_fill(void* host, int i, float noise_w, float length_scale, unsigned gen, unsigned seed);
 bool flow_seam_eligible(int H, int half);
@@ -1102,6 +1106,10 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   float* x1 = ar.f32(B * (size_t)H * T);
   float* qkv = ar.f32(B * (size_t)3 * H * T);
   float* att = ar.f32(B * (size_t)H * T);
+  // long rows: the attention core runs key-split in two parts plus a merge (attention.hip); scratch for the parts, shared by the layers
+  const int att_parts = rel_attention_split_parts(ctx, NB, c.n_heads, H / std::max(1, c.n_heads), T, c.window);
+  float* att_po = att_parts > 1 ? ar.f32(B * (size_t)att_parts * H * T) : nullptr;
+  float* att_pml = att_parts > 1 ? ar.f32(B * (size_t)c.n_heads * att_parts * 2 * T) : nullptr;
   float* y = ar.f32(B * (size_t)H * T);
   float* ff = ar.f32(B * (size_t)c.ffn * T);
   float* stats = ar.f32(B * (size_t)2 * I * T);
@@ -1191,6 +1199,9 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
       const float *ek = L.ek, *ev = L.ev;
       const int nh = c.n_heads, w = c.window;
       st.run = [=](hipStream_t q) {
+        if (att_parts > 1)
+          return launch_rel_attention_split(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
+                                            (int64_t)3 * H * T, (int64_t)H * T, lensT, att_parts, att_po, att_pml);
         return launch_rel_attention(ctx, q, qkv, qkv + (size_t)H * T, qkv + (size_t)2 * H * T, ek, ev, att, NB, nh, d, T, w,
                                     (int64_t)3 * H * T, (int64_t)H * T, lensT);
       };

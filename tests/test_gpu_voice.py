@@ -323,6 +323,31 @@ def test_ragged_batch_and_bucketed_plans(rt_medium, voices):
     assert_close(a2[:60 * 256], orc.synthesize(cfg, blob, ids2, dur2, None, 0.667), WAVE_TOL, "warm plan, new utterance")
 
 
+def test_key_split_attention_with_true_lengths(rt_medium, voices):
+    """Rows of more than one key tile run the attention core key-split (parts + merge kernel); the number of parts a block sees
+    depends on the item's TRUE length, not on the bucket: a 2-item batch in the T = 304 bucket whose items end inside the third and
+    inside the second key tile, each against the oracle run alone (enc_out tap and waveform)."""
+    cfg, blob = voices["medium"]
+    rng = np.random.RandomState(33)
+    utts = []
+    for b, T in enumerate((300, 150)):
+        ids = rng.randint(0, 130, size=T).tolist()
+        dur = [1] * T
+        utts.append((ids, dur, kd.sym(SD + 950 + b, (192, T), 1.7320508)))
+    rt_medium.prepare_batch(13, utts, 0.667)
+    assert rt_medium.plan_info(13)["bucket_t"] == 304
+    rt_medium.launch(13)
+    audio = rt_medium.collect(13)
+    enc = rt_medium.tap(13, "enc_out", sum(192 * len(u[0]) for u in utts))
+    off = eoff = 0
+    for b, (ids, dur, noise) in enumerate(utts):
+        ref, taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+        assert_close(enc[eoff:eoff + 192 * len(ids)], taps["enc_out"], OP_TOL, f"key-split item {b}: enc_out")
+        assert_close(audio[off:off + len(ids) * 256], ref, WAVE_TOL, f"key-split item {b}: audio")
+        off += len(ids) * 256
+        eoff += 192 * len(ids)
+
+
 def test_plan_cache_is_bounded_and_lru(backend, voices):
     """More distinct buckets than the cache holds: idle plans are evicted least-recently-used first, attached ones never."""
     cfg, blob = voices["medium"]
