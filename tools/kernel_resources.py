@@ -60,13 +60,13 @@ def main():
         if len(kern) > 40:  # the streamed conv templates: a summary row per kernel name is enough
             groups = {}
             for n, r in kern:
-                groups.setdefault(re.sub(r"<.*", "", n.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("ph::detail::", "")), []).append(r)
+                groups.setdefault(re.sub(r"<.*", "", n.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("ph::detail::", "")), []).append(r)
             for g, rs in groups.items():
                 f = lambda k: f"{min(r.get(k, 0) for r in rs)}–{max(r.get(k, 0) for r in rs)}"
                 lines.append(f"| `{g}` × {len(rs)} instantiations | {f('NumVgprs')} | {f('NumAgprs')} | {f('TotalNumSgprs')} | {f('ScratchSize')} | {f('LDSByteSize')} | {f('Occupancy')} | {f('codeLenInByte')} |")
         else:
             for n, r in kern:
-                n = n.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("ph::detail::", "")
+                n = n.replace("void ", "").replace("ph::(anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("ph::detail::", "")
                 n = re.sub(r"\(.*", "", n)
                 lines.append(f"| `{n[:90]}` | {r.get('NumVgprs', 0)} | {r.get('NumAgprs', 0)} | {r.get('TotalNumSgprs', 0)} | {r.get('ScratchSize', 0)} | {r.get('LDSByteSize', 0)} | "
                              f"{r.get('Occupancy', 0)} | {r.get('codeLenInByte', 0)} |")
