@@ -972,8 +972,12 @@ int build_generator_merged(piper_hip_voice* v, Slot& s, Arena& ar, float* dec0, 
       s.steps.push_back(std::move(st));
     };
     // two chained convs per launch, intermediate in LDS (rb_pair.hip): ResBlock1 — (convs1[di], convs2[di]); ResBlock2 —
-    // steps (di, di+1). PIPER_HIP_NO_RB_PAIR=1 keeps the conv-by-conv schedule (A/B).
-    static const bool no_pair = getenv("PIPER_HIP_NO_RB_PAIR") != nullptr;
+    // steps (di, di+1). PIPER_HIP_NO_RB_PAIR=1 keeps the conv-by-conv schedule (A/B). Very short utterances (under 128 frames in the
+    // launch: factors 1 and 2) leave the pair kernel's 256-column tiles too few blocks — 41 at factor 1 — and run conv by conv
+    // (r2: factor 1 0.649 → 0.620 ms, factor 2 0.670 → 0.659; from factor 4 on the pair kernel wins). PIPER_HIP_RB_PAIR_MIN_F moves it.
+    static const bool no_pair_env = getenv("PIPER_HIP_NO_RB_PAIR") != nullptr;
+    static const int64_t pair_min_f = [] { const char* e = getenv("PIPER_HIP_RB_PAIR_MIN_F"); return e ? atoll(e) : 128ll; }();
+    const bool no_pair = no_pair_env || (int64_t)F * NB < pair_min_f;
     auto add_pair = [&](const std::string& name, int ia, int ib, const int da[kWinMulti], const int db[kWinMulti], bool res_a, bool res_b_x,
                         const float* const x[kWinMulti], float* const y[kWinMulti]) {
       struct Pack { RbPairArgs a[kWinMulti]; } pk;
