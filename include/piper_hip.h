@@ -476,7 +476,7 @@ int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const char* name_f
 /* ---- multi-GPU: the path's one collective --------------------------------------------------------------------
  * Utterances are independent, so N GPUs are N replicas of the voice, one process per GPU; the only exchange is the one-shot
  * broadcast of the voice blob from the rank that parsed the .onnx (PiperMetalRuntime.init(modelPath:) does that parse once per
- * process, PiperMetalGraph.swift:25-41). These wrap rccl.h so that a host without torch.distributed (the Swift CLI, a C++
+ * process, PiperMetalRuntime.swift:37-41 → ONNXModel.init). These wrap rccl.h so that a host without torch.distributed (the Swift CLI, a C++
  * server) can do it: rank 0 calls comm_unique_id and hands the 128 bytes to the other ranks by any side channel (a file, a
  * socket, an environment variable), every rank calls comm_create (collective), uploads / allocates n_floats on its GPU,
  * calls comm_broadcast_f32 (collective, in place, returns when the data is there) and piper_hip_voice_create(on_device = 1).

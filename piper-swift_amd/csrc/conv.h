@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* x3 = nullptr;
   const float* w = nullptr;   // MFMA path: packed 32-wide fragments (pack_conv_weights); direct path: raw ONNX layout
   const float* w16 = nullptr; // optional packed 16-wide fragments (short-utterance geometry)
+  const float* w16g = nullptr; // gated convs: 16-wide fragments with 8 tanh rows + their 8 sigmoid rows per tile (pack_conv_weights_gate16; conv_short.hip)
   const float* bias = nullptr;
   const float* res = nullptr;   // residual / minuend, same addressing as y
   const float* skip = nullptr;  // EPI_WN_*: running skip sum, same addressing as y2 (may be null)
@@ -84,6 +85,8 @@ size_t packed_conv_floats(int Cout, int Cin, int K, int tm = 32);
 size_t packed_convt_floats(int Cin, int Cout, int K, int s, int tm = 32);
 int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed, int tm = 32);
 int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed, int tm = 32);
+// gated conv (Cout = 2·H rows, tanh half then sigmoid half): 16-row tiles of rows {8m … 8m+7} ∪ {H + 8m … H + 8m+7}; same size as the tm = 16 image
+int pack_conv_weights_gate16(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
 // tile geometry launch_conv_mfma will pick for this problem when 16-wide fragments are available (32 or 16)
 int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate);
 
@@ -91,6 +94,9 @@ int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate);
 bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups);
 // Enqueue one conv on `s`. args.w must already be packed for the MFMA path.
 int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
+// Short rows (one utterance's encoder / flow convs): conv_short.hip. 1 = enqueued, 0 = not this kernel's case (use launch_conv_mfma's
+// streaming kernel), < 0 = error. Called by launch_conv_mfma.
+int try_launch_conv_short(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
 // Thread-per-output kernel for everything else (groups, stride, tiny Cout). args.w is raw [Cout, Cin/g, K].
 int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
 // Thread-per-output ConvTranspose for geometries the phase decomposition does not cover. w raw [Cin, Cout/g, K].

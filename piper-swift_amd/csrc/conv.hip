@@ -35,7 +35,7 @@ namespace {
 
 // ---- weight packing (once per voice; per call for the op-level API) ----
 __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
-                                                           int K, int mtiles, int nsteps, int tm) {
+                                                           int K, int mtiles, int nsteps, int tm, int gate_half) {
   const int cps = tm == 32 ? 2 : 4;
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -43,8 +43,15 @@ __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restri
     const int64_t ms = i >> 6;
     const int step = (int)(ms % nsteps), mt = (int)(ms / nsteps);
     const int cp = step / K, tap = step - cp * K;  // steps beyond the real channel pairs are zero padding
-    const int co = mt * tm + (lane & (tm - 1)), ci = cps * cp + lane / tm;
-    out[i] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * K + tap] : 0.0f;
+    int co = mt * tm + (lane & (tm - 1));
+    const int ci = cps * cp + lane / tm;
+    bool row_ok = co < Cout;
+    if (gate_half) {  // tile row i < 8: tanh row 8·mt + i; i ≥ 8: its sigmoid partner gate_half + 8·mt + i − 8
+      const int i16 = lane & 15, h = 8 * mt + (i16 & 7);
+      row_ok = h < gate_half;
+      co = (i16 < 8 ? 0 : gate_half) + h;
+    }
+    out[i] = (row_ok && ci < Cin) ? w[((int64_t)co * Cin + ci) * K + tap] : 0.0f;
   }
 }
 
@@ -368,7 +375,16 @@ int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, f
   const int64_t total = (int64_t)mtiles * nsteps * 64;
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps, tm);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps, tm, 0);
+  return PIPER_HIP_OK;
+}
+
+int pack_conv_weights_gate16(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed) {
+  const int mtiles = (int)ceil_div(Cout, 16), nsteps = padded_steps(Cin, K, 16);
+  const int64_t total = (int64_t)mtiles * nsteps * 64;
+  if (total == 0) return PIPER_HIP_OK;
+  const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps, 16, Cout / 2);
   return PIPER_HIP_OK;
 }
 
@@ -414,6 +430,11 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_tile launch failed: %s", hipGetErrorString(e));
     return PIPER_HIP_OK;
+  }
+  {  // short rows with few tiles: the LDS-window kernel (conv_short.hip)
+    const int r = try_launch_conv_short(ctx, s, a);
+    if (r < 0) return r;
+    if (r == 1) return PIPER_HIP_OK;
   }
   // Tile geometry: 16×16 tiles when 32×32 tiles alone cannot give every CU one (short utterances) and the caller has
   // the 16-wide fragment image.

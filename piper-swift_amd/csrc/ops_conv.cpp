@@ -287,6 +287,13 @@ PH_EXPORT int piper_hip_wavenet_layer_f32(piper_hip_ctx* ctx, const float* x, co
   ConvArgs a;  // in_conv + tanh·sigmoid gate
   a.x = x; a.bias = b_in; a.y = acts;
   if (tm_in == 16) a.w16 = p_in; else a.w = p_in;
+  if (tm_in == 16 && dilation == 1) {  // short rows: the gate-interleaved image of conv_short.hip (8 tanh rows + their 8 sigmoid rows per tile)
+    float* p_g = nullptr;
+    if ((rc = pool_floats(ctx, packed_conv_floats(2 * C, C, K, 16), &p_g))) return rc;
+    defer_free(ctx, p_g);
+    pack_conv_weights_gate16(ss.s, w_in, 2 * C, C, K, p_g);
+    a.w16g = p_g;
+  }
   a.N = (int)n; a.Cin = C; a.Cout = 2 * C; a.K = K; a.dil = (int)dilation; a.padL = (int)((k * dilation - dilation) / 2);
   a.Lin = T; a.Lout = T; a.x_batch_stride = (int64_t)C * T; a.y_batch_stride = (int64_t)C * T; a.y_len = T; a.gate = 1;
   if ((rc = launch_conv_mfma(ctx, ss.s, a))) return rc;

@@ -2,7 +2,7 @@
 //
 // Reference: the generator's ResBlocks are chains of "x ← x + conv_d(lrelu(x))" (ResBlock2, Piper medium) or
 // "x ← x + conv_1(lrelu(conv_d(lrelu(x))))" (ResBlock1, Piper high) — GraphExecutor dispatches every LeakyRelu / Conv / Add of
-// them on its own (PiperMetalGraph.swift: the `dec.resblocks.*` nodes; conv1d.metal:28-71 is the conv). conv_win_kernel runs
+// them on its own (GraphExecutor.swift:2047-2069 LeakyRelu, :1739-1810 Conv, :861-899 Add; conv1d.metal:28-71 is the conv). conv_win_kernel runs
 // one conv per launch: per conv it reads x (window) + the residual and writes the result — three fp32 passes over a
 // [C × L] tensor — and each 32×32 output tile pays a full block prologue (window staging, weight-ring start) and epilogue for
 // as little as 48 MFMAs. Measured on medium/factor 8 (r2 PMC, tools/probe/run_pmc.sh): 13 vector + 13 scalar instructions

@@ -162,6 +162,7 @@ struct Step {
 struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bias pointer into the resident blob
   const float* w = nullptr;
   const float* w16 = nullptr;  // 16-wide fragment image (short-utterance geometry)
+  const float* w16g = nullptr; // the same for a gated conv: 8 tanh rows + their 8 sigmoid rows per tile
   const float* w4 = nullptr;   // conv_win_kernel fragment image (generator convs: long rows)
   const float* w5 = nullptr;   // conv_pipe_kernel fragment image (chunk-major step order; Cin % 32 == 0)
   const float* bias = nullptr;
@@ -318,7 +319,7 @@ struct Packer {  // bump allocator over the packed-weights allocation
 };
 
 // Registers one conv. dry = true only measures the packed size.
-ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true, bool win = false) {
+ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true, bool win = false, bool gated = false) {
   ConvW c;
   c.Cout = Cout; c.Cin = Cin; c.K = K;
   c.mfma = conv_mfma_eligible(Cout, Cin, K, 1, 1);
@@ -331,6 +332,11 @@ ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int C
     float* p16 = pk.take(packed_conv_floats(Cout, Cin, K, 16));
     if (!dry) pack_conv_weights(pk.s, w, Cout, Cin, K, p16, 16);
     c.w16 = p16;
+    if (gated && Cout % 16 == 0) {  // tanh / sigmoid rows interleaved per 16-row tile (conv_short.hip)
+      float* pg = pk.take(packed_conv_floats(Cout, Cin, K, 16));
+      if (!dry) pack_conv_weights_gate16(pk.s, w, Cout, Cin, K, pg);
+      c.w16g = pg;
+    }
     if (win) {
       float* p4 = pk.take(packed_conv_win_floats(Cout, Cin, K));
       if (!dry) pack_conv_weights_win(pk.s, w, Cout, Cin, K, p4);
@@ -395,7 +401,7 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
     C.pre = make_conv(pk, dry, nm, H, I / 2, 1);
     for (int i = 0; i < c.wn_layers; i++) {
       snprintf(nm, sizeof nm, "flow.flows.%d.enc.in_layers.%d", 2 * f, i);
-      C.in.push_back(make_conv(pk, dry, nm, 2 * H, H, c.wn_kernel));
+      C.in.push_back(make_conv(pk, dry, nm, 2 * H, H, c.wn_kernel, true, false, true));
       snprintf(nm, sizeof nm, "flow.flows.%d.enc.res_skip_layers.%d", 2 * f, i);
       C.rs.push_back(make_conv(pk, dry, nm, (i + 1 < c.wn_layers) ? 2 * H : H, H, 1));
     }
@@ -544,6 +550,7 @@ double conv_bytes(int Cin, int Cout, int K, int64_t L) { return 4.0 * ((double)C
 void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW& w, ConvArgs a, int64_t Lout_for_work) {
   a.w = w.w;
   a.w16 = w.w16;
+  a.w16g = w.w16g;
   a.bias = w.bias;
   a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K;
   piper_hip_ctx* ctx = v->ctx;

@@ -1,6 +1,7 @@
 """The stochastic duration predictor (Piper `dp`: DDSConv stacks, reverse ConvFlows with the inverse rational-quadratic
 spline, ElementwiseAffine; exp · length_scale · ceil). Reference call site: PiperMetalRuntime.synthesize runs the whole graph,
-PiperMetalGraph.swift:1124 lists the ops (Erf, Softplus, Softmax, CumSum, GatherND, ScatterND, Where …) this restates.
+the op arms this restates are GraphExecutor.swift:1946 (Erf), :1957 (Softplus), :1917 (Softmax), :2604 (CumSum), :2493 (GatherND),
+:2379 (ScatterND), :1699 (Where), :2470 (NonZero), :699 (GatherElements).
 
 CPU: the C oracle against tests/golden/dp.npz (torch restatement, itself 0.0 from transformers' VitsStochasticDurationPredictor).
 GPU: piper_hip_voice_predict_durations and prepare(durations = NULL) against the oracle."""

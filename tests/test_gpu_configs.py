@@ -1,5 +1,5 @@
 """GPU: the BASELINE.json configurations at their REAL sizes, each against the fp32 oracle (not against this library's own
-output): configs[2] factor 64 (encoder / flow taps, attention at T = 896), configs[3] the 32 mixed-length utterances
+output): configs[2] factor 64 (encoder / flow taps AND the whole waveform, attention at T = 896), configs[3] the 32 mixed-length utterances
 (one by one on slots and bucketed by shape), configs[4] high voice + bf16 generator at factor 8, and the streamed
 utterance. The oracle legs are the slow part (≈ 1–15 s each on 16 host threads); the file runs in about a minute."""
 import numpy as np
@@ -35,26 +35,26 @@ def rt_medium(backend, voices):
     rt.close()
 
 
-def test_config2_factor64_encoder_and_flow_vs_oracle(rt_medium, voices):
-    """BASELINE configs[2]: 896 ids, 2 688 frames. enc_out, m_p/logs_p, z_p and z against the oracle's text encoder and
-    reverse flow at the full length (the generator at this size is covered by test_full_size_properties)."""
+def test_config2_factor64_whole_utterance_vs_oracle(rt_medium, voices):
+    """BASELINE configs[2]: 896 ids, 2 688 frames, 688 128 samples. ONE oracle run of the whole utterance (≈ 185 GFLOP on the
+    host threads): enc_out, m_p / logs_p, z_p, z AND the whole waveform against it — the generator at this size is compared
+    with the oracle itself, not with this library's own op-level composition (VERDICT r2 weak #1)."""
     cfg, blob = voices["medium"]
     ids, dur, noise = utt(64, SD + 1)
     T, F, I, H = len(ids), 3 * len(ids), cfg.inter, cfg.hidden
     rt_medium.prepare(0, ids, dur, noise, 0.667)
     rt_medium.launch(0)
     audio = rt_medium.collect(0)
-    assert audio.size == F * cfg.hop and np.all(np.isfinite(audio))
-    enc_ref, stats_ref = orc.text_encoder(cfg, blob, ids)
-    assert_close(rt_medium.tap(0, "enc_out", H * T), enc_ref, OP_TOL, "enc_out @T=896")
-    assert_close(rt_medium.tap(0, "m_p", I * T), stats_ref[:I], OP_TOL, "m_p @T=896")
-    assert_close(rt_medium.tap(0, "logs_p", I * T), stats_ref[I:], OP_TOL, "logs_p @T=896")
-    f2t = np.repeat(np.arange(T), dur)
-    zp_ref = stats_ref[:I][:, f2t] + (noise * np.exp(stats_ref[I:][:, f2t])) * np.float32(0.667)
-    zp = rt_medium.tap(0, "z_p", I * F)
-    assert_close(zp, zp_ref, OP_TOL, "z_p @F=2688")
-    z_ref = orc.flow_reverse(cfg, blob, zp.reshape(I, F))
-    assert_close(rt_medium.tap(0, "z", I * F), z_ref, OP_TOL, "z @F=2688")
+    assert audio.size == F * cfg.hop == 688128 and np.all(np.isfinite(audio))
+    ref, taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+    assert_close(rt_medium.tap(0, "enc_out", H * T), taps["enc_out"], OP_TOL, "enc_out @T=896")
+    assert_close(rt_medium.tap(0, "m_p", I * T), taps["m_p"], OP_TOL, "m_p @T=896")
+    assert_close(rt_medium.tap(0, "logs_p", I * T), taps["logs_p"], OP_TOL, "logs_p @T=896")
+    assert_close(rt_medium.tap(0, "z_p", I * F), taps["z_p"], OP_TOL, "z_p @F=2688")
+    assert_close(rt_medium.tap(0, "z", I * F), taps["z"], OP_TOL, "z @F=2688")
+    err = float(np.abs(audio - ref).max())
+    print(f"factor 64 waveform vs oracle: max|Δ| = {err:.3e} over {audio.size} samples")
+    assert_close(audio, ref, WAVE_TOL, "factor 64 waveform (688 128 samples) vs oracle")
 
 
 @pytest.mark.parametrize("T", [896, 301])

@@ -5,7 +5,7 @@ ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$ROOT"
 mkdir -p tools/probe/bin /tmp/sp_obj
 F="-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -w -DPH_STREAM_TRACE"
-for f in conv conv_inst_k1 conv_inst_k2 conv_inst_k3 conv_inst_k5 conv_inst_k7 conv_inst_k11 conv_win conv_pipe; do
+for f in conv conv_short conv_inst_k1 conv_inst_k2 conv_inst_k3 conv_inst_k5 conv_inst_k7 conv_inst_k11 conv_win conv_pipe; do
   /opt/rocm/bin/hipcc $F -c -x hip piper-swift_amd/csrc/$f.hip -o /tmp/sp_obj/$f.o &
 done
 /opt/rocm/bin/hipcc $F -c -x hip piper-swift_amd/csrc/context.cpp -o /tmp/sp_obj/context.o &

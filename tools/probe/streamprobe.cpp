@@ -30,8 +30,10 @@ int main(int argc, char** argv) {
   (void)hipMemset(b, 0, Cout * 4);
   pack_conv_weights(s, w, Cout, Cin, K, p32);
   pack_conv_weights(s, w, Cout, Cin, K, p16, 16);
+  float* p16g = nullptr;
+  if (gate) { (void)hipMalloc(&p16g, packed_conv_floats(Cout, Cin, K, 16) * 4); pack_conv_weights_gate16(s, w, Cout, Cin, K, p16g); }
   ConvArgs a;
-  a.x = x; a.y = y; a.w = p32; a.w16 = p16; a.bias = b; a.N = 1; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = 1; a.padL = (K - 1) / 2; a.Lin = L; a.Lout = L;
+  a.x = x; a.y = y; a.w = p32; a.w16 = p16; a.w16g = p16g; a.bias = b; a.N = 1; a.Cin = Cin; a.Cout = Cout; a.K = K; a.dil = 1; a.padL = (K - 1) / 2; a.Lin = L; a.Lout = L;
   a.x_batch_stride = (int64_t)Cin * L; a.y_batch_stride = (int64_t)rows_out * L; a.y_len = L; a.gate = gate;
   if (relu) a.epilogue = EPI_RELU;
   (void)hipStreamSynchronize(s);
