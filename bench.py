@@ -31,8 +31,8 @@ FIXTURE_IDS = [1, 20, 0, 120, 0, 61, 0, 24, 0, 59, 0, 100, 0, 2]  # bench/fixtur
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (no sparsity)
 HBM_PEAK_GBS = 8000.0
-PROFILE_F32 = "r2_rocprof_summary.json"  # committed PMC passes of `python bench.py` (see profiles/README.md)
-PROFILE_BF16 = "r2_high_bf16_rocprof_summary.json"
+PROFILE_F32 = "r3_rocprof_summary.json"  # committed PMC passes of `python bench.py` (see profiles/README.md)
+PROFILE_BF16 = "r3_high_bf16_rocprof_summary.json"
 
 
 def utterance(factor, seed, inter=192):
@@ -61,21 +61,71 @@ def _free_port():
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without torchrun: this process never touches the GPU (no HIP call, no torch.cuda, not even
-    an `import torch`); it starts N children — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — relays rank 0's
-    single JSON line and fails if any rank fails. (A process that has initialised the GPU must not exec or fork workers.)"""
+    an `import torch`); it starts N FRESH children — one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set — relays rank
+    0's single JSON line and fails if any rank fails. (A process that has initialised the GPU must not exec or fork workers.)
+
+    Every child is supervised, not only rank 0: the first rank to exit non-zero (import error, hipSetDevice failure, an RCCL
+    error …) takes the others down at once — they would otherwise sit in the rendezvous or in a collective until a store /
+    watchdog timeout — its stderr tail is printed and the launcher exits 1. An overall deadline (PIPER_BENCH_DEADLINE_S,
+    default 900 s) bounds a hang that produces no exit code at all."""
     import subprocess
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(_free_port())
-    procs = []
+    deadline = time.monotonic() + float(os.environ.get("PIPER_BENCH_DEADLINE_S", "900"))
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        err = tempfile.TemporaryFile()
+        logs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.startswith("{")]
-    if any(rcs) or len(lines) != 1:
-        sys.stderr.write(f"bench.py: ranks exited with {rcs}; rank 0 printed {len(lines)} JSON line(s)\n")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err))
+
+    def tail(f, nbytes=2000):
+        f.seek(0, 2)
+        size = f.tell()
+        f.seek(max(0, size - nbytes))
+        return f.read().decode("utf-8", "replace")
+
+    def stop_all():
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        t_end = time.monotonic() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
+
+    failed = None
+    while True:
+        rcs = [q.poll() for q in procs]
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = (bad[0], rcs[bad[0]], "exited")
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = (next(i for i, rc in enumerate(rcs) if rc is None), None, "still running at the deadline")
+            break
+        time.sleep(0.05)
+    if failed:
+        stop_all()
+        r, rc, what = failed
+        sys.stderr.write(f"bench.py: rank {r} {what} (exit code {rc}); the other ranks were stopped. Its stderr tail:\n{tail(logs[r])}\n")
+        raise SystemExit(1)
+    for r, f in enumerate(logs):  # pass the ranks' diagnostics on (warnings, the one-rank notes)
+        t = tail(f, 4000)
+        if t.strip():
+            sys.stderr.write(t if r == 0 else "".join(f"[rank {r}] {ln}\n" for ln in t.splitlines()))
+    out0.seek(0)
+    lines = [ln for ln in out0.read().decode("utf-8", "replace").splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: all {n} ranks exited 0 but rank 0 printed {len(lines)} JSON line(s)\n")
         raise SystemExit(1)
     print(lines[0], flush=True)
 
@@ -89,6 +139,9 @@ def dry_run(args, rank, world, saved_stdout):
     import torch.distributed as dist
     import piper_hip as ph
     from piper_hip import distributed as phd
+    if os.environ.get("PIPER_BENCH_DRY_FAIL_RANK") == str(rank):  # fault injection for tests/: this rank dies before the rendezvous
+        sys.stderr.write(f"injected failure on rank {rank}\n")
+        raise SystemExit(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = ph.voice_config(args.quality)
     n = ph.blob_floats(cfg)
@@ -192,11 +245,25 @@ def main():
         backend = ph.HipBackend(local_rank)
         # the same broadcast once more through the library's own C-ABI (piper_hip_comm_* over rccl.h — what a host without
         # torch.distributed would call); its result must equal what torch.distributed delivered
+        # Every rank must take the SAME path through the collectives below: a rank that skipped one (librccl not loadable by the
+        # library, id creation failed on rank 0) while the others entered it would hang the job, not report an error. So the ranks
+        # first agree — MIN over ranks of "RCCL is usable through the C-ABI here" (rank 0's flag includes creating the id) — and
+        # the rehearsal runs on all ranks or on none.
+        uid, why = None, ""
         try:
+            usable = 1 if ph.comm_available() else 0
+            if usable and rank == 0:
+                uid = ph.comm_unique_id()
+        except Exception as e:
+            usable, why = 0, repr(e)
+        flag = torch.tensor([usable], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
             idt = torch.zeros(ph.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
             if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(ph.comm_unique_id()), dtype=torch.uint8))
+                idt.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
             dist.broadcast(idt, 0)
+            # from here on an error is fatal for the whole job (the launcher stops the other ranks): the collectives are matched
             comm = ph.Comm(backend, idt.cpu().numpy().tobytes(), rank, world)
             w2 = wbuf.clone() if rank == 0 else torch.zeros_like(wbuf)
             torch.cuda.synchronize()
@@ -207,8 +274,8 @@ def main():
             comm_info = {"world": comm.world, "broadcast_ms": round(c_ms, 3), "equals_torch_broadcast": bool(torch.equal(w2, wbuf))}
             comm.close()
             del w2
-        except Exception as e:  # reported, never fatal: the torch.distributed broadcast above already delivered the blob
-            comm_info = {"error": repr(e)}
+        else:
+            comm_info = {"skipped": "piper_hip_comm_* not usable on every rank" + (f" (this rank: {why})" if why else "")}
         rt = ph.HipRuntime(backend, cfg, wbuf.data_ptr(), on_device=True)
         keep.append(wbuf)
     else:
@@ -401,25 +468,26 @@ def main():
             m_us = avg_us * n_l
             peak_tf = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
             achieved = m_fl / (m_us * 1e-6) / 1e12 if m_us > 0 else 0.0
-            traffic = None
+            traffic, traffic_commit = None, None
             try:  # HBM bytes per launch of these kernel families from the committed PMC passes of the same command
                 def per_launch(path, families):
                     pj = json.load(open(os.path.join(ROOT, "profiles", path)))
                     fam = [pj["traffic"][f] for f in families if f in pj["traffic"]]
                     n = sum(f["launches"] for f in fam)
-                    return sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None
+                    return (sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None), pj.get("commit")
                 if args.factor == 8 and args.quality == "medium" and not bf16:
-                    traffic = per_launch(PROFILE_F32, ("conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel", "rb_pair_kernel"))
+                    traffic, traffic_commit = per_launch(PROFILE_F32, ("conv_short_kernel", "conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel", "rb_pair_kernel"))
                 elif args.factor == 8 and args.quality == "high" and bf16:
-                    traffic = per_launch(PROFILE_BF16, ("conv_bf16_kernel",))
+                    traffic, traffic_commit = per_launch(PROFILE_BF16, ("conv_bf16_kernel", "rb_pair_bf16_kernel"))
             except Exception:
                 pass
             out["roofline"] = {
                 "kernel": ("conv_bf16_kernel (bf16-operand MFMA Conv1d/ConvTranspose1d of the generator, LDS-resident input window; all of its launches in one utterance)"
                            if bf16 else
-                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_stream_kernel for short rows, conv_win_kernel / rb_pair_kernel for the generator long rows; all of their launches in one utterance)"),
+                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_short_kernel / conv_stream_kernel for short rows, conv_win_kernel / rb_pair_kernel for the generator long rows; all of their launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
+                "traffic_profile_commit": traffic_commit,  # the tree the PMC passes were taken on (tools/collect_profiles.sh stamps it)
                 "traffic_note": f"HBM bytes per launch from profiles/{PROFILE_BF16 if bf16 else PROFILE_F32}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                 "passes of this command, (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md; algorithmic bytes per launch "
                                 f"= {m_by / max(1, n_l) / 1e6:.2f} MB",
@@ -565,12 +633,19 @@ def main():
             for _ in range(reps):
                 orc.synthesize(cfg, blob, ids, dur, noise, 0.667)
             dt = (time.perf_counter() - a) / reps
-            out["cpu_baseline"] = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
-                                   "cores": cores, "kind": "port",
-                                   "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
+            port = {"value": round(audio_sec / dt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(dt * 1e3, 1),
+                    "cores": cores, "kind": "port",
+                    "sample": f"{reps} utterance of the same factor-{args.factor} workload (oracle/piper_oracle.c, OpenMP over output channels)"}
             # SURVEY.md §8d fallback (ii): PyTorch-CPU eager fp32 on the same synthetic graph (tests/torch_ref.py, library conv /
             # matmul kernels) — the closest stand-in for the ORT-CPU baseline the north star names (onnxruntime and a Piper
-            # .onnx are not available offline). Reported beside the naive port, not instead of it.
+            # .onnx are not available offline). It is the meaningful CPU figure, so it is `cpu_baseline`; the naive port (the
+            # parity oracle, written for clarity, not speed) stays beside it as `cpu_baseline_port`.
+            cpu_model = ""
+            try:
+                cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+            except Exception:
+                pass
+            port["cpu"] = cpu_model
             try:
                 import torch
                 import torch_ref
@@ -583,17 +658,13 @@ def main():
                     for _ in range(treps):
                         tref.synthesize(ids, dur, noise, 0.667)
                     tdt = (time.perf_counter() - a) / treps
-                cpu_model = ""
-                try:
-                    cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
-                except Exception:
-                    pass
-                out["cpu_baseline_torch"] = {"value": round(audio_sec / tdt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(tdt * 1e3, 2),
-                                             "cores": cores, "kind": "torch-cpu-eager-fp32", "torch": torch.__version__, "cpu": cpu_model,
-                                             "sample": f"{treps} utterances of the same factor-{args.factor} workload after 1 warm-up (tests/torch_ref.py)"}
-                out["cpu_baseline"]["cpu"] = cpu_model
-            except Exception as e:  # torch missing on the box: say so, do not substitute
-                out["cpu_baseline_torch"] = {"unavailable": repr(e)}
+                out["cpu_baseline"] = {"value": round(audio_sec / tdt, 3), "unit": "audio-sec/wall-sec", "ms_per_utterance": round(tdt * 1e3, 2),
+                                       "cores": cores, "kind": "torch-cpu-eager-fp32", "torch": torch.__version__, "cpu": cpu_model,
+                                       "sample": f"{treps} utterances of the same factor-{args.factor} workload after 1 warm-up (tests/torch_ref.py)",
+                                       "note": "stands in for the ORT-CPU provider the north star names (onnxruntime / a Piper .onnx are not available offline)"}
+                out["cpu_baseline_port"] = port
+            except Exception as e:  # torch missing on the box: the port is the baseline, and the line says why
+                out["cpu_baseline"] = dict(port, torch_unavailable=repr(e))
         if batch32 is not None:
             out["batch32"] = batch32
         sys.stdout.flush()

@@ -622,6 +622,16 @@ def comm_unique_id():
     return buf.raw
 
 
+def comm_available():
+    """True when the library can reach RCCL here (librccl.so.1 loads and ncclGetUniqueId works). Local, not a collective — what
+    every rank checks BEFORE the ranks agree to enter piper_hip_comm_* together (bench.py)."""
+    try:
+        comm_unique_id()
+        return True
+    except Exception:
+        return False
+
+
 class Comm:
     """piper_hip_comm_*: an RCCL communicator for the one-shot voice-blob broadcast (and the bench's MAX / barrier)."""
 

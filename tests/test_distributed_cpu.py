@@ -98,3 +98,30 @@ def test_bench_launcher_spawns_ranks_dry():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_launcher_stops_everyone_when_one_rank_dies():
+    """a rank other than 0 that dies before the rendezvous used to leave rank 0 waiting in it until a store
+    timeout. The launcher supervises every child: the first non-zero exit stops the siblings and the launcher returns non-zero
+    within seconds, naming the rank and showing its stderr."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PIPER_BENCH_DRY="1", PIPER_BENCH_DRY_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    took = time.monotonic() - t0
+    assert r.returncode != 0
+    assert "rank 1 exited" in r.stderr and "injected failure on rank 1" in r.stderr, r.stderr[-2000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]  # no half-baked result line
+    assert took < 60, f"launcher needed {took:.0f} s to notice a dead rank"
+    # the overall deadline bounds a hang that never produces an exit code
+    env2 = dict(env, PIPER_BENCH_DEADLINE_S="0.5")
+    env2.pop("PIPER_BENCH_DRY_FAIL_RANK")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                        env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "deadline" in r2.stderr

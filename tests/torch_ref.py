@@ -3,7 +3,7 @@
 Independent of oracle/piper_oracle.c (different language, library ops instead of loops). Three users:
   * tools/gen_golden.py writes tests/golden/*.npz from it (run in the build container only),
   * tests/test_hf_crosscheck.py pins it against the third-party VITS implementation in `transformers.models.vits`,
-  * bench.py's `cpu_baseline_torch` leg times it on the GPU box's host cores (SURVEY.md §8d fallback (ii)).
+  * bench.py's `cpu_baseline` leg times it on the GPU box's host cores (SURVEY.md §8d fallback (ii)).
 Nothing under piper-swift_amd/ imports it.
 """
 import os
