@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PIPER_HIP_ABI_VERSION 2
+#define PIPER_HIP_ABI_VERSION 3
 
 /* ---- status codes: ExecutionError (CPUBackend.swift:3-17) + NSError domain "MetalBackend" ---- */
 enum {
@@ -355,7 +355,17 @@ int piper_hip_onnx_initializer(const piper_hip_onnx* m, int index, piper_hip_onn
 int piper_hip_onnx_find(const piper_hip_onnx* m, const char* name); /* initializer index or -1 */
 int piper_hip_onnx_read_f32(const piper_hip_onnx* m, int index, float* dst, size_t n);
 int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voice_config* cfg);
+/* Is the node graph the computation this library's fixed launch schedule performs for `cfg`? The reference executes whatever the graph
+ * says (GraphExecutor.swift:227-265); this library does not look at the nodes when it runs, so it looks at them HERE: header (opset 15,
+ * I/O names, Gather first — ONNXParsingTests.swift:22-36), op census (the 50 arms of GraphExecutor.swift:592-2659), every Conv /
+ * ConvTranspose's attributes and effective padding, the attention / skew / softmax / LayerNorm(eps) / FFN structure per encoder layer,
+ * Flips and tanh·sigmoid gates of the flow, LeakyRelu slopes, residual Adds and the MRF mean of the generator, the RandomNormalLike count.
+ * PIPER_HIP_ERR_UNSUPPORTED + a message naming the first differing node otherwise (csrc/onnx_verify.cpp). */
+int piper_hip_onnx_verify_graph(const piper_hip_onnx* m, const piper_hip_voice_config* cfg);
+/* build_blob = verify_graph, then the initializers in layout order. _unchecked skips the verification: for weight containers that carry
+ * no graph; the caller vouches that the weights belong to a standard Piper VITS. */
 int piper_hip_onnx_build_blob(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats);
+int piper_hip_onnx_build_blob_unchecked(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats);
 /* The numbers this library needs from the voice's `.onnx.json` (PiperConfig.swift:3-47). */
 typedef struct {
   int32_t sample_rate, num_symbols, num_speakers;

@@ -60,43 +60,10 @@ struct Reader {  // protobuf wire format
   }
 };
 
-struct Tensor {
-  std::string name;
-  int dtype = 0;  // ONNX TensorProto.DataType: 1 = FLOAT, 7 = INT64
-  std::vector<int64_t> dims;
-  const uint8_t* raw = nullptr;  size_t raw_len = 0;    // field 9
-  const uint8_t* fdat = nullptr; size_t fdat_len = 0;   // field 4, packed
-  std::vector<float> floats_unpacked;                    // field 4, unpacked encoding (rare)
-  int64_t count() const {  // -1 for negative dims or a product that does not fit (hostile / corrupt files)
-    int64_t n = 1;
-    for (int64_t d : dims) {
-      if (d < 0 || (d != 0 && n > INT64_MAX / d)) return -1;
-      n *= d;
-    }
-    return n;
-  }
-};
-
-struct ConvNode {  // Conv / ConvTranspose with an initializer as weight
-  std::string op, weight, bias, name;
-  int64_t stride = 1, dilation = 1, group = 1, pad_l = 0, pad_r = 0;
-};
-
 }  // namespace
 
-struct piper_hip_onnx {
-  std::vector<uint8_t> owned;          // open_memory copy
-  const uint8_t* data = nullptr;
-  size_t size = 0;
-  void* map = nullptr;
-  size_t map_len = 0;
-  int64_t ir_version = 0, opset = 0;
-  int n_nodes = 0;
-  std::vector<Tensor> tensors;
-  std::map<std::string, int> by_name;
-  std::map<std::string, ConvNode> conv_by_weight;
-  std::map<std::string, ConvNode> conv_by_node;  // by NodeProto.name ("/flow/flows.0/enc/in_layers.0/Conv")
-};
+#include "onnx_model.h"
+using namespace ph::onnx;
 
 namespace {
 
@@ -118,6 +85,11 @@ bool parse_tensor(Reader r, Tensor& t) {
       if (r.end - r.p < 4) return false;
       float f; memcpy(&f, r.p, 4); r.p += 4;
       t.floats_unpacked.push_back(f);
+    } else if (field == 7 && wire == 2) {  // int64_data, packed (Constant tensors)
+      Reader d = r.sub();
+      while (!d.at_end()) t.i64_unpacked.push_back((int64_t)d.varint());
+    } else if (field == 7 && wire == 0) {
+      t.i64_unpacked.push_back((int64_t)r.varint());
     } else if (field == 8 && wire == 2) {
       Reader d = r.sub();
       t.name.assign((const char*)d.p, (size_t)(d.end - d.p));
@@ -132,58 +104,71 @@ bool parse_tensor(Reader r, Tensor& t) {
 }
 
 bool parse_node(Reader r, piper_hip_onnx* m) {
-  std::vector<std::string> inputs;
-  std::string op, node_name;
+  Node nd;
   ConvNode c;
-  bool has_pads = false;
   while (!r.at_end()) {
     const uint64_t tag = r.varint();
     const int field = (int)(tag >> 3), wire = (int)(tag & 7);
     if (field == 1 && wire == 2) {
       Reader d = r.sub();
-      inputs.emplace_back((const char*)d.p, (size_t)(d.end - d.p));
+      nd.inputs.emplace_back((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 2 && wire == 2) {
+      Reader d = r.sub();
+      nd.outputs.emplace_back((const char*)d.p, (size_t)(d.end - d.p));
     } else if (field == 3 && wire == 2) {
       Reader d = r.sub();
-      node_name.assign((const char*)d.p, (size_t)(d.end - d.p));
+      nd.name.assign((const char*)d.p, (size_t)(d.end - d.p));
     } else if (field == 4 && wire == 2) {
       Reader d = r.sub();
-      op.assign((const char*)d.p, (size_t)(d.end - d.p));
-    } else if (field == 5 && wire == 2) {  // AttributeProto
+      nd.op.assign((const char*)d.p, (size_t)(d.end - d.p));
+    } else if (field == 5 && wire == 2) {  // AttributeProto: 1 name, 2 f, 3 i, 4 s, 5 t, 8 ints (ONNXLoader.swift:214-223)
       Reader a = r.sub();
-      std::string an;
-      std::vector<int64_t> ints;
-      int64_t iv = 0;
-      bool has_i = false;
+      Attr at;
       while (!a.at_end()) {
         const uint64_t t2 = a.varint();
         const int f2 = (int)(t2 >> 3), w2 = (int)(t2 & 7);
-        if (f2 == 1 && w2 == 2) { Reader d = a.sub(); an.assign((const char*)d.p, (size_t)(d.end - d.p)); }
-        else if (f2 == 3 && w2 == 0) { iv = (int64_t)a.varint(); has_i = true; }
-        else if (f2 == 8 && w2 == 2) { Reader d = a.sub(); while (!d.at_end()) ints.push_back((int64_t)d.varint()); }
-        else if (f2 == 8 && w2 == 0) ints.push_back((int64_t)a.varint());
+        if (f2 == 1 && w2 == 2) { Reader d = a.sub(); at.name.assign((const char*)d.p, (size_t)(d.end - d.p)); }
+        else if (f2 == 2 && w2 == 5) { if (a.end - a.p < 4) return false; memcpy(&at.f, a.p, 4); a.p += 4; at.has_f = true; }
+        else if (f2 == 3 && w2 == 0) { at.i = (int64_t)a.varint(); at.has_i = true; }
+        else if (f2 == 4 && w2 == 2) { Reader d = a.sub(); at.s.assign((const char*)d.p, (size_t)(d.end - d.p)); }
+        else if (f2 == 5 && w2 == 2) { if (!parse_tensor(a.sub(), at.t)) return false; at.has_t = true; }
+        else if (f2 == 8 && w2 == 2) { Reader d = a.sub(); while (!d.at_end()) at.ints.push_back((int64_t)d.varint()); }
+        else if (f2 == 8 && w2 == 0) at.ints.push_back((int64_t)a.varint());
         else a.skip(w2);
       }
       if (!a.ok) return false;
-      if (an == "strides" && !ints.empty()) c.stride = ints[0];
-      else if (an == "dilations" && !ints.empty()) c.dilation = ints[0];
-      else if (an == "group" && has_i) c.group = iv;
-      else if (an == "pads" && ints.size() >= 2) { c.pad_l = ints[0]; c.pad_r = ints[ints.size() / 2]; has_pads = true; }
+      if (at.name == "strides" && !at.ints.empty()) c.stride = at.ints[0];
+      else if (at.name == "dilations" && !at.ints.empty()) c.dilation = at.ints[0];
+      else if (at.name == "group" && at.has_i) c.group = at.i;
+      else if (at.name == "pads" && at.ints.size() >= 2) { c.pad_l = at.ints[0]; c.pad_r = at.ints[at.ints.size() / 2]; }
+      nd.attrs.push_back(std::move(at));
     } else {
       r.skip(wire);
     }
   }
-  (void)has_pads;
   if (!r.ok) return false;
   m->n_nodes++;
-  if ((op == "Conv" || op == "ConvTranspose") && inputs.size() >= 2) {
-    c.op = op;
-    c.weight = inputs[1];
-    if (inputs.size() >= 3) c.bias = inputs[2];
-    c.name = node_name;
+  if ((nd.op == "Conv" || nd.op == "ConvTranspose") && nd.inputs.size() >= 2) {
+    c.op = nd.op;
+    c.weight = nd.inputs[1];
+    if (nd.inputs.size() >= 3) c.bias = nd.inputs[2];
+    c.name = nd.name;
     m->conv_by_weight[c.weight] = c;
-    if (!node_name.empty()) m->conv_by_node[node_name] = c;
+    if (!nd.name.empty()) m->conv_by_node[nd.name] = c;
   }
+  m->nodes.push_back(std::move(nd));
   return true;
+}
+
+// ValueInfoProto{1 name}: graph inputs / outputs (GraphProto 11 / 12, ONNXLoader.swift:94-99)
+std::string value_info_name(Reader r) {
+  std::string name;
+  while (!r.at_end()) {
+    const uint64_t tag = r.varint();
+    if ((tag >> 3) == 1 && (tag & 7) == 2) { Reader d = r.sub(); name.assign((const char*)d.p, (size_t)(d.end - d.p)); }
+    else r.skip((int)(tag & 7));
+  }
+  return name;
 }
 
 int parse_model(piper_hip_onnx* m) {
@@ -218,6 +203,10 @@ int parse_model(piper_hip_onnx* m) {
           if (!parse_tensor(g.sub(), t)) PH_FAIL(PIPER_HIP_ERR_ARG, "onnx: malformed TensorProto");
           m->by_name[t.name] = (int)m->tensors.size();
           m->tensors.push_back(std::move(t));
+        } else if (f2 == 11 && w2 == 2) {
+          m->graph_inputs.push_back(value_info_name(g.sub()));
+        } else if (f2 == 12 && w2 == 2) {
+          m->graph_outputs.push_back(value_info_name(g.sub()));
         } else {
           g.skip(w2);
         }
@@ -322,7 +311,9 @@ void fill_visit(const piper_tensor_desc* d, void* user) {
   if (b->rc) return;
   const std::string name = d->name;
   float* dst = b->blob + d->offset;
-  if (const Tensor* t = resolve(b->m, name)) {
+  // a weight-norm pair left in the export takes precedence over whatever the module's node lists as its weight input
+  const bool wn_pair = !find(b->m, name) && find(b->m, name + "_g") && find(b->m, name + "_v");
+  if (const Tensor* t = wn_pair ? nullptr : resolve(b->m, name)) {
     // shape check: same element count and, when ranks agree, the same dims
     if ((int)t->dims.size() == d->rank)
       for (int i = 0; i < d->rank; i++)
@@ -522,6 +513,14 @@ PH_EXPORT int piper_hip_onnx_infer_config(const piper_hip_onnx* m, piper_hip_voi
 }
 
 PH_EXPORT int piper_hip_onnx_build_blob(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats) {
+  if (!m || !cfg || !host_blob) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  // the weights are only handed out for a graph that IS the computation the schedule performs (onnx_verify.cpp)
+  const int vrc = piper_hip_onnx_verify_graph(m, cfg);
+  if (vrc) return vrc;
+  return piper_hip_onnx_build_blob_unchecked(m, cfg, host_blob, n_floats);
+}
+
+PH_EXPORT int piper_hip_onnx_build_blob_unchecked(const piper_hip_onnx* m, const piper_hip_voice_config* cfg, float* host_blob, size_t n_floats) {
   if (!m || !cfg || !host_blob) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
   size_t need = 0;
   int rc = piper_hip_voice_blob_floats(cfg, &need);

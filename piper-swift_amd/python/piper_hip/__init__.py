@@ -183,6 +183,8 @@ _PROTOS = {
     "piper_hip_onnx_read_f32": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_size_t]),
     "piper_hip_onnx_infer_config": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
     "piper_hip_onnx_build_blob": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
+    "piper_hip_onnx_build_blob_unchecked": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
+    "piper_hip_onnx_verify_graph": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
     "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
     "piper_hip_voice_check_json": (C.c_int, [C.POINTER(VoiceConfig), C.POINTER(PiperJsonInfo)]),
     "piper_hip_pcm16_from_f32": (C.c_int, [c_f32p, C.c_size_t, C.POINTER(C.c_int16)]),
@@ -713,14 +715,20 @@ class OnnxModel:
         _check(self.lib.piper_hip_onnx_infer_config(self.h, C.byref(cfg)))
         return cfg
 
-    def build_blob(self, cfg):
+    def verify_graph(self, cfg):
+        """Raises (UNSUPPORTED, naming the first differing node) unless the node graph is the computation the launch schedule performs."""
+        _check(self.lib.piper_hip_onnx_verify_graph(self.h, C.byref(cfg)))
+
+    def build_blob(self, cfg, verify=True):
         blob = np.empty(blob_floats(cfg), np.float32)
-        _check(self.lib.piper_hip_onnx_build_blob(self.h, C.byref(cfg), blob.ctypes.data_as(c_f32p), blob.size))
+        fn = self.lib.piper_hip_onnx_build_blob if verify else self.lib.piper_hip_onnx_build_blob_unchecked
+        _check(fn(self.h, C.byref(cfg), blob.ctypes.data_as(c_f32p), blob.size))
         return blob
 
 
-def load_voice(onnx_path, json_path=None):
-    """(cfg, blob, json info) of a Piper voice: `<voice>.onnx` + `<voice>.onnx.json` (PiperVoices layout)."""
+def load_voice(onnx_path, json_path=None, verify=True):
+    """(cfg, blob, json info) of a Piper voice: `<voice>.onnx` + `<voice>.onnx.json` (PiperVoices layout). The node graph is verified
+    against the launch schedule (refused otherwise) unless verify=False."""
     m = OnnxModel(onnx_path)
     try:
         cfg = m.infer_config()
@@ -730,7 +738,7 @@ def load_voice(onnx_path, json_path=None):
             info = piper_json(open(jp, "r", encoding="utf-8").read())
             _check(load_library().piper_hip_voice_check_json(C.byref(cfg), C.byref(info)))  # multi-speaker / vocabulary mismatch
             cfg.sample_rate = info.sample_rate
-        return cfg, m.build_blob(cfg), info
+        return cfg, m.build_blob(cfg, verify), info
     finally:
         m.close()
 

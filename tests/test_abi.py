@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/piper_hip.h but not exported"
     # and the python shim binds exactly the declared set
     assert sorted(ph.exported_symbols()) == syms
-    assert lib.piper_hip_abi_version() == 2
+    assert lib.piper_hip_abi_version() == 3
 
 
 def test_no_oracle_in_product():

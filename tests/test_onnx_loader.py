@@ -95,8 +95,10 @@ def test_onnx_errors(voices, tmp_path):
     m.close()
     data = ow.model([], [ow.tensor(t["name"], t["shape"], blob[t["offset"]:t["offset"] + t["count"]].reshape(t["shape"])) for t in short])
     m = ph.OnnxModel(data=data)
+    with pytest.raises(ph.UnsupportedOp):
+        m.build_blob(cfg)  # a file without the node graph is refused outright …
     with pytest.raises(ph.ExecutionError) as e:
-        m.build_blob(cfg)
+        m.build_blob(cfg, verify=False)  # … and as a bare weight container it still reports what is missing
     assert "flow.flows.2.post.bias" in str(e.value)
     m.close()
     # wrong dtype for a float tensor
@@ -104,7 +106,7 @@ def test_onnx_errors(voices, tmp_path):
     bad.insert(0, ow.tensor(lay[0]["name"], lay[0]["shape"], np.zeros(lay[0]["shape"], np.int64)))
     m = ph.OnnxModel(data=ow.model([], bad))
     with pytest.raises(ph.TypeMismatch):
-        m.build_blob(cfg)
+        m.build_blob(cfg, verify=False)
     m.close()
 
 
@@ -166,7 +168,7 @@ def test_onnx_reader_under_sanitizers(tmp_path):
     csrc = os.path.join(root, "piper-swift_amd", "csrc")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(root, "tools", "fuzz", "fuzz_onnx.cpp"),
-                           os.path.join(csrc, "onnx_loader.cpp"), os.path.join(csrc, "voice_blob.cpp"), "-o", str(exe)])
+                           os.path.join(csrc, "onnx_loader.cpp"), os.path.join(csrc, "onnx_verify.cpp"), os.path.join(csrc, "voice_blob.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe), str(seed), "1500"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "no sanitizer report" in out.stdout
@@ -235,3 +237,58 @@ def test_config_validation_bounds():
     bad(hidden=1 << 20)
     bad(up_rates=(0, 1000))
     assert ph.blob_floats(ph.voice_config("high")) == 27798784 or ph.blob_floats(ph.voice_config("high")) > 0
+
+
+# ---- graph verifier (csrc/onnx_verify.cpp): the node graph must BE the computation the fixed launch schedule performs ----
+
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_graph_verifier_accepts_the_piper_export(quality, voices):
+    """The full inference graph (onnx_writer.GraphBuilder: opset 15, Gather first, scope-named nodes, Constant scalars, LayerNorm as
+    the ReduceMean chain, the skew as Pad / Reshape / Slice, Flip as a step −1 Slice, masks as Mul) passes — also with weight-norm
+    pairs left in and with constant-folded anonymous conv weights."""
+    cfg, blob = voices[quality]
+    lay = layout_dicts(cfg)
+    for kw in ({}, {"weight_norm": {"dec.conv_pre.weight", "flow.flows.0.enc.in_layers.1.weight"}},
+               {"anonymous": {"dec.ups.0", "flow.flows.2.enc.res_skip_layers.0", "dec.resblocks.1.convs.1" if cfg.resblock_type == 2 else "dec.resblocks.1.convs1.1"}}):
+        m = ph.OnnxModel(data=ow.piper_voice_onnx(cfg, blob, lay, **kw))
+        m.verify_graph(m.infer_config())
+        assert m.counts()["nodes"] > 800
+        m.close()
+
+
+MUTATIONS = [  # (defect planted by the writer, what the refusal must name)
+    ("lrelu_alpha", "alpha 0.2"), ("ln_eps", "epsilon"), ("extra_node", "Relu_extra"), ("res_op", "not added to the ResBlock"),
+    ("conv_pads", "effective padding (0, 0)"), ("mrf_div", "divides by 4"), ("out_act", "Tanh"), ("bad_op", "Einsum"),
+    ("gate_swap", "half of the in_layer output"), ("no_flip", "Flips"), ("wn_dilation", "dilation 2"), ("softmax_axis", "axis 1"),
+    ("softmax_op", "expected Softmax"), ("q_scale", "1/sqrt(head_dim"), ("ffn_act", "expected Relu"), ("emb_scale", "sqrt(hidden)"),
+    ("extra_rng", "RandomNormalLike"), ("extra_first", "first node"),
+]
+
+
+@pytest.mark.parametrize("mut,needle", MUTATIONS)
+def test_graph_verifier_refuses_a_graph_that_differs(mut, needle, voices):
+    """VERDICT r2 missing #1: a voice whose export differs in op order, slope, epsilon, padding or an extra node used to load and render
+    wrong audio. Every planted defect is refused (UnsupportedOp), the message names the node / the assumption, and the weights are not
+    handed out (build_blob fails the same way)."""
+    cfg, blob = voices["medium"]
+    m = ph.OnnxModel(data=ow.piper_voice_onnx(cfg, blob, layout_dicts(cfg), mut=mut))
+    with pytest.raises(ph.UnsupportedOp) as e:
+        m.verify_graph(cfg)
+    assert needle in str(e.value), str(e.value)
+    with pytest.raises(ph.UnsupportedOp):
+        m.build_blob(cfg)
+    m.close()
+
+
+def test_graph_verifier_header_and_sparse_graph(voices):
+    cfg, blob = voices["medium"]
+    lay = layout_dicts(cfg)
+    for kw, needle in (({"opset": 13}, "opset 13"), ({"inputs": ("input", "input_lengths", "scales", "sid")}, "multi-speaker"),
+                       ({"outputs": ("audio",)}, "outputs"), ({"graph": "sparse"}, "embedding is not scaled")):
+        m = ph.OnnxModel(data=ow.piper_voice_onnx(cfg, blob, lay, **kw))
+        with pytest.raises(ph.UnsupportedOp) as e:
+            m.verify_graph(cfg)
+        assert needle in str(e.value), str(e.value)
+        if kw.get("graph") == "sparse":  # the initializers are fine: the caller may vouch for them explicitly
+            assert np.array_equal(m.build_blob(cfg, verify=False), blob)
+        m.close()

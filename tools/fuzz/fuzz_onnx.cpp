@@ -1,5 +1,5 @@
 // fuzz_onnx.cpp — sanitizer harness for the ONNX reader (host-only): every prefix of a seed model and N random byte
-// mutations go through open → infer_config → build_blob. Built with g++ -fsanitize=address,undefined (CPU only; GPU
+// mutations go through open → infer_config → verify_graph → build_blob. Built with g++ -fsanitize=address,undefined (CPU only; GPU
 // sanitizers are not available on the pool). The library sources are compiled in directly; error text goes to a stub.
 #include <cstdarg>
 #include <cstdint>
@@ -49,7 +49,8 @@ static int try_model(const uint8_t* data, size_t n) {
     size_t nf = 0;
     if (piper_hip_voice_blob_floats(&cfg, &nf) == PIPER_HIP_OK && nf < (64u << 20)) {
       std::vector<float> blob(nf);
-      (void)piper_hip_onnx_build_blob(m, &cfg, blob.data(), nf);
+      (void)piper_hip_onnx_build_blob(m, &cfg, blob.data(), nf);            // graph verifier, then the initializers
+      (void)piper_hip_onnx_build_blob_unchecked(m, &cfg, blob.data(), nf);  // the initializers alone
       parsed = 2;
     }
   }
