@@ -292,6 +292,99 @@ __global__ __launch_bounds__(BT) void conv_cout1_wide_kernel(const ConvArgs p) {
   }
 }
 
+// The same conv on SHORT rows (one utterance of a few seconds: 84 … 300 blocks of 1 024 outputs would leave most CUs idle, and the one-wave
+// 256-output blocks of round 2 left three of a CU's four SIMDs idle while each wave issued ≈ 4 300 vector instructions — r3 PMC
+// SQ_INSTS_VALU — a third of them the correctly rounded divisions of the MRF mean). Here a 256-output block is FOUR waves that split
+// the input channels (wave w takes channels 8w … 8w+7 of every group of 32), each staging its own eight rows in its own piece of LDS
+// (no block barrier between chunks), and the four partial sums meet once at the end: 4 × the waves, a quarter of the work each.
+// The mean is x·(1/3) here — one rounding step from the graph's Add, Add, Div (≤ 1 ulp; the oracle comparison stays at WAVE_TOL).
+template <int PRO>
+__global__ __launch_bounds__(256) void conv_cout1_split_kernel(const ConvArgs p) {
+  constexpr int kOut = 256, kW = kOut + 16;
+  __shared__ __attribute__((aligned(16))) float xs_all[4 * kWideCK * kW];
+  __shared__ __attribute__((aligned(16))) float ws[256 * 8];  // [Cin ≤ 256][8]: 7 taps + a zero
+  __shared__ float red[4 * kOut];
+  constexpr bool AVG = PRO == PRO_AVG3_LRELU;
+  const int n = blockIdx.y, t0 = blockIdx.x * kOut, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Lv = true_len(p, n);
+  if (p.len_ptr && t0 >= Lv) return;  // block-uniform: every output lies past the true length
+  float* xs = xs_all + wave * (kWideCK * kW);
+  const int la = t0 - 4;               // aligned position of window column 0 (t0 − pad = la + 1)
+  const float* xb = p.x + (int64_t)n * p.x_batch_stride;
+  const float* x2b = AVG ? p.x2 + (int64_t)n * p.x_batch_stride : nullptr;
+  const float* x3b = AVG ? p.x3 + (int64_t)n * p.x_batch_stride : nullptr;
+  for (int i = tid; i < p.Cin * 8; i += 256) ws[i] = (i & 7) < kWideK ? p.w[(i >> 3) * kWideK + (i & 7)] : 0.0f;
+  float4 t[kWideCK + 1], t2[AVG ? kWideCK + 1 : 1], t3[AVG ? kWideCK + 1 : 1];
+  auto slot = [&](int q, int& row, int& i4) {  // staging slot q of this lane → (row, float4 column); row ≥ kWideCK: none
+    row = q < kWideCK ? q : (lane < 32 ? (lane >> 2) : kWideCK);
+    i4 = q < kWideCK ? lane : 64 + (lane & 3);
+  };
+  auto issue = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q <= kWideCK; q++) {
+      int row, i4;
+      slot(q, row, i4);
+      const int pos = la + 4 * i4;
+      const int c = min(c0 + min(row, kWideCK - 1), p.Cin - 1);
+      const int64_t off = (int64_t)c * p.Lin + ((pos >= 0 && pos < p.Lin) ? pos : 0);
+      t[q] = *(const float4*)(xb + off);
+      if constexpr (AVG) { t2[q] = *(const float4*)(x2b + off); t3[q] = *(const float4*)(x3b + off); }
+    }
+  };
+  constexpr float third = 1.0f / 3.0f;
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q <= kWideCK; q++) {
+      int row, i4;
+      slot(q, row, i4);
+      const int pos = la + 4 * i4;
+      const int nvalid = (pos >= 0 && pos < p.Lin && c0 + row < p.Cin) ? Lv - pos : 0;
+      float4 v = t[q];
+      if constexpr (AVG) {
+        v.x = ((v.x + t2[q].x) + t3[q].x) * third; v.y = ((v.y + t2[q].y) + t3[q].y) * third;
+        v.z = ((v.z + t2[q].z) + t3[q].z) * third; v.w = ((v.w + t2[q].w) + t3[q].w) * third;
+      }
+      if constexpr (PRO != PRO_NONE) { v.x = lrelu(v.x, p.alpha); v.y = lrelu(v.y, p.alpha); v.z = lrelu(v.z, p.alpha); v.w = lrelu(v.w, p.alpha); }
+      v.x = nvalid > 0 ? v.x : 0.0f; v.y = nvalid > 1 ? v.y : 0.0f; v.z = nvalid > 2 ? v.z : 0.0f; v.w = nvalid > 3 ? v.w : 0.0f;
+      if (row < kWideCK) *(float4*)(xs + row * kW + 4 * i4) = v;
+    }
+  };
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int c_first = wave * kWideCK;
+  if (c_first < p.Cin) issue(c_first);
+  __syncthreads();  // ws is complete
+  for (int c0 = c_first; c0 < p.Cin; c0 += 4 * kWideCK) {
+    commit(c0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (c0 + 4 * kWideCK < p.Cin) issue(c0 + 4 * kWideCK);
+    const int ck = min(kWideCK, p.Cin - c0);
+    for (int c = 0; c < ck; c++) {
+      const float4* xr = (const float4*)(xs + c * kW + 4 * lane);
+      const float4 v0 = xr[0], v1 = xr[1], v2 = xr[2], v3 = xr[3];
+      const float4 w0 = *(const float4*)(ws + (c0 + c) * 8), w1 = *(const float4*)(ws + (c0 + c) * 8 + 4);
+      const float v[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+      const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int k = 0; k < kWideK; k++)
+#pragma unroll
+        for (int o = 0; o < 4; o++) acc[o] += v[1 + o + k] * w[k];  // output 4·lane + o, tap k: window column 4·lane + 1 + o + k
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  *(float4*)(red + wave * kOut + 4 * lane) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  // thread tid finishes output tid: bias first, then the four channel groups in order (deterministic)
+  float v = p.bias ? p.bias[0] : 0.0f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; w2++) v += red[w2 * kOut + tid];
+  const int xo = t0 + tid;
+  if (xo < p.Lout) store_elem(p, n, 0, xo, v);
+}
+
 template <int BT>
 void launch_wide(hipStream_t s, const ConvArgs& a) {
   const dim3 g((unsigned)ceil_div(a.Lout, 4 * BT), (unsigned)a.N);
@@ -526,8 +619,17 @@ int launch_conv_direct(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a) {
       ((uintptr_t)a.x & 15) == 0 && a.Lin >= wide_min &&
       (a.prologue != PRO_AVG3_LRELU || ((((uintptr_t)a.x2 | (uintptr_t)a.x3) & 15) == 0)) &&
       (a.epilogue == EPI_STORE || a.epilogue == EPI_TANH) && !a.res && !a.gate) {
-    if (ceil_div(a.Lout, 1024) * a.N < 2 * ctx->num_cus) launch_wide<64>(s, a);
-    else launch_wide<256>(s, a);
+    static const bool no_split = getenv("PIPER_HIP_NO_POST_SPLIT") != nullptr;
+    if (ceil_div(a.Lout, 1024) * a.N < 2 * ctx->num_cus) {
+      if (!no_split) {  // short rows: 256-output blocks of four channel-splitting waves
+        const dim3 g((unsigned)ceil_div(a.Lout, 256), (unsigned)a.N);
+        switch (a.prologue) {
+          case PRO_NONE: hipLaunchKernelGGL((conv_cout1_split_kernel<PRO_NONE>), g, dim3(256), 0, s, a); break;
+          case PRO_LRELU: hipLaunchKernelGGL((conv_cout1_split_kernel<PRO_LRELU>), g, dim3(256), 0, s, a); break;
+          default: hipLaunchKernelGGL((conv_cout1_split_kernel<PRO_AVG3_LRELU>), g, dim3(256), 0, s, a); break;
+        }
+      } else launch_wide<64>(s, a);
+    } else launch_wide<256>(s, a);
     hipError_t e3 = hipGetLastError();
     if (e3 != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_cout1_wide launch failed: %s", hipGetErrorString(e3));
     return PIPER_HIP_OK;
