@@ -429,6 +429,12 @@ int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance*
  * instantiate once ("cold"). Reports the bucket of a prepared slot and the cache's size. */
 int piper_hip_voice_plan_info(const piper_hip_voice* v, int slot, int32_t* bucket_t, int32_t* bucket_f, int32_t* cached_plans,
                               size_t* cached_bytes);
+/* Bounds of the voice's plan cache: at most `max_plans` plans and `max_bytes` of arenas (0 = the default 24 GiB) are kept; idle plans are
+ * evicted least recently used first, plans attached to a slot never. Defaults: 128 plans. */
+int piper_hip_voice_set_plan_cache(piper_hip_voice* v, int max_plans, size_t max_bytes);
+/* Wall milliseconds of the phases of the LATEST plan build (a "cold" prepare): [0] stream / events, [1] schedule construction + arena
+ * allocation, [2] arena initialisation, [3] eager validation pass, [4] graph capture, [5] graph instantiate. */
+int piper_hip_voice_last_build_breakdown(const piper_hip_voice* v, double out_ms[6]);
 /* Batch size of a prepared slot (0 if the slot is not prepared). */
 int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot);
 /* Enqueue the prepared slot's forward pass (one hipGraphLaunch). No host sync. */

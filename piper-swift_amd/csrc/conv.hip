@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BT) void conv_cout1_wide_kernel(const ConvArgs p) {
 // SQ_INSTS_VALU — a third of them the correctly rounded divisions of the MRF mean). Here a 256-output block is FOUR waves that split
 // the input channels (wave w takes channels 8w … 8w+7 of every group of 32), each staging its own eight rows in its own piece of LDS
 // (no block barrier between chunks), and the four partial sums meet once at the end: 4 × the waves, a quarter of the work each.
-// The mean is x·(1/3) here — one rounding step from the graph's Add, Add, Div (≤ 1 ulp; the oracle comparison stays at WAVE_TOL).
+// The mean is x·(1/3) here — one rounding step from the graph's Add, Add, Div (≤ 1 ulp, far inside the stated waveform tolerance).
 template <int PRO>
 __global__ __launch_bounds__(256) void conv_cout1_split_kernel(const ConvArgs p) {
   constexpr int kOut = 256, kW = kOut + 16;

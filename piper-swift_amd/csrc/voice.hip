@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <functional>
 #include <memory>
 
@@ -184,6 +185,7 @@ struct Slot {
   int T = -1, F = -1, NB = 1;
   int prec = 0;            // generator precision the schedule was built for
   bool in_use = false;     // attached to a user slot id
+  bool built = false;      // schedule + arena exist; `exec` (the captured graph) follows after the plan's FIRST run, which goes out eagerly
   uint64_t last_use = 0;   // voice-wide clock value of the last attach (LRU)
   size_t arena_bytes = 0;
   int* lensT = nullptr;    // [NB] device: true phoneme count per item
@@ -289,6 +291,16 @@ struct piper_hip_voice {
   // Plans are cached voice-wide, least-recently-used first out; a user slot id is a handle on one of them. A TTS server sees
   // a new (T, F) almost every call: with buckets the plan for it usually exists already (prepare = input upload only).
   std::vector<std::unique_ptr<Slot>> plans;
+  struct StreamSet { hipStream_t stream, side[2]; hipEvent_t ev0, ev1, ev_fork, ev_join[2]; };
+  std::vector<StreamSet> free_sets;  // streams / events of evicted plans, reused by the next build (a HIP stream costs ≈ 3 ms to create)
+  double last_build_ms[6] = {0, 0, 0, 0, 0, 0};  // the latest plan build: stream/events, schedule + arena, arena init, eager pass, capture, instantiate
+  size_t plan_cache_max = 128, plan_cache_bytes = (size_t)24 << 30;
+  // Page-locked staging of a slot id's inputs and of its (short) waveform: it belongs to the SLOT ID, not to the plan attached to it —
+  // a new bucket then costs no hipHostMalloc (≈ 0.3–1 ms each, four per plan until round 3). Grown in powers of two, freed with the voice.
+  struct Staging {
+    int64_t* h_ids = nullptr; int32_t* h_f2i = nullptr; int* h_lens = nullptr; float* h_audio = nullptr;
+    size_t cap_t = 0, cap_f = 0, cap_lens = 0, audio_cap = 0;
+  } staging[kMaxSlots];
   Slot* attached[kMaxSlots] = {};
   uint64_t use_clock = 0;
   int hop = 1;
@@ -504,22 +516,15 @@ void slot_release(piper_hip_voice* v, Slot& s, bool all) {
   s.steps.clear();
   s.taps.clear();
   s.T = s.F = -1;
-  if (all && s.inited) {
-    if (s.h_ids) (void)hipHostFree(s.h_ids);
-    if (s.h_f2i) (void)hipHostFree(s.h_f2i);
-    if (s.h_lens) (void)hipHostFree(s.h_lens);
-    if (s.h_audio) (void)hipHostFree(s.h_audio);
+  s.built = false;
+  if (all) {  // (host buffers belong to the plan whether or not it currently holds a stream set)
+    // (the pinned staging buffers are the slot id's: piper_hip_voice::staging)
     if (s.ev_in) (void)hipEventDestroy(s.ev_in);
     s.ev_in = nullptr;
     s.h_ids = nullptr; s.h_f2i = nullptr; s.h_lens = nullptr; s.h_audio = nullptr; s.h_cap_t = s.h_cap_f = s.h_cap_lens = 0; s.h_audio_cap = 0;
-    if (s.ev0) (void)hipEventDestroy(s.ev0);
-    if (s.ev1) (void)hipEventDestroy(s.ev1);
-    if (s.ev_fork) (void)hipEventDestroy(s.ev_fork);
-    for (int i = 0; i < 2; i++) {
-      if (s.ev_join[i]) (void)hipEventDestroy(s.ev_join[i]);
-      if (s.side[i]) (void)hipStreamDestroy(s.side[i]);
-    }
-    if (s.stream) (void)hipStreamDestroy(s.stream);
+    // streams and events go back to the voice (the caller has synchronised them); piper_hip_voice_destroy destroys them
+    if (s.stream) v->free_sets.push_back({s.stream, {s.side[0], s.side[1]}, s.ev0, s.ev1, s.ev_fork, {s.ev_join[0], s.ev_join[1]}});
+    s.stream = nullptr; s.side[0] = s.side[1] = nullptr; s.ev0 = s.ev1 = s.ev_fork = nullptr; s.ev_join[0] = s.ev_join[1] = nullptr;
     s.inited = false;
   }
 }
@@ -1614,7 +1619,13 @@ int build_duration_predictor(piper_hip_voice* v, Slot& s, Arena& ar, const float
   return PIPER_HIP_OK;
 }
 
+int ensure_side_streams(Slot& s);
+
 int run_schedule(Slot& s, hipStream_t q, bool parallel) {
+  if (parallel) {
+    const int rc0 = ensure_side_streams(s);
+    if (rc0) return rc0;
+  }
   for (auto& st : s.steps) {
     if (st.kind == Step::FORK) {
       if (parallel) {
@@ -1642,15 +1653,29 @@ int run_schedule(Slot& s, hipStream_t q, bool parallel) {
 
 int slot_init(piper_hip_voice* v, Slot& s) {
   if (s.inited) return PIPER_HIP_OK;
+  if (!v->free_sets.empty()) {  // a set an evicted plan left behind
+    const auto st = v->free_sets.back();
+    v->free_sets.pop_back();
+    s.stream = st.stream; s.side[0] = st.side[0]; s.side[1] = st.side[1];
+    s.ev0 = st.ev0; s.ev1 = st.ev1; s.ev_fork = st.ev_fork; s.ev_join[0] = st.ev_join[0]; s.ev_join[1] = st.ev_join[1];
+    s.inited = true;
+    return PIPER_HIP_OK;
+  }
+  // r3 (tools/probe/cold_prepare.py): creating the three streams of a plan was 8.6–10 ms of an 11 ms plan build. The two side
+  // streams are only for schedules with parallel branches (ensure_side_streams), so a plan now creates one.
   PH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev0), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev1), PIPER_HIP_ERR_LAUNCH);
-  for (int i = 0; i < 2; i++) {
-    PH_HIP(hipStreamCreateWithFlags(&s.side[i], hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
-    PH_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
-  }
-  PH_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
   s.inited = true;
+  return PIPER_HIP_OK;
+}
+
+int ensure_side_streams(Slot& s) {
+  for (int i = 0; i < 2; i++) {
+    if (!s.side[i]) PH_HIP(hipStreamCreateWithFlags(&s.side[i], hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
+    if (!s.ev_join[i]) PH_HIP(hipEventCreateWithFlags(&s.ev_join[i], hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
+  }
+  if (!s.ev_fork) PH_HIP(hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;
 }
 
@@ -1821,6 +1846,18 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
   (void)hipSetDevice(v->ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& pl : v->plans) slot_release(v, *pl, true);
+  for (auto& sg : v->staging) {
+    if (sg.h_ids) (void)hipHostFree(sg.h_ids);
+    if (sg.h_f2i) (void)hipHostFree(sg.h_f2i);
+    if (sg.h_lens) (void)hipHostFree(sg.h_lens);
+    if (sg.h_audio) (void)hipHostFree(sg.h_audio);
+  }
+  for (auto& st : v->free_sets) {
+    for (hipEvent_t e : {st.ev0, st.ev1, st.ev_fork, st.ev_join[0], st.ev_join[1]})
+      if (e) (void)hipEventDestroy(e);
+    for (hipStream_t q : {st.side[0], st.side[1], st.stream})
+      if (q) (void)hipStreamDestroy(q);
+  }
   for (void* p : v->owned) (void)v->ctx->pool.release(p);
   delete v;
 }
@@ -1839,18 +1876,19 @@ namespace {
 int bucket_t(int T) { return (int)ceil_div(T, 16) * 16; }
 int bucket_f(int F) { return F <= 1024 ? (int)ceil_div(F, 16) * 16 : (int)ceil_div(F, 64) * 64; }
 
-constexpr size_t kPlanCacheMax = 48;                    // plans kept per voice …
+constexpr size_t kPlanCacheMax = 128;                   // default plans kept per voice (r3: 48 → 128; an idle plan holds an arena, no stream) …
 constexpr size_t kPlanCacheBytes = (size_t)24 << 30;    // … and arena bytes (of 288 GB): least recently used idle plans go first
+// (piper_hip_voice_set_plan_cache changes both per voice)
 
 Slot* slot_plan(const piper_hip_voice* v, int slot) {
   if (!v || slot < 0 || slot >= kMaxSlots) return nullptr;
   Slot* p = v->attached[slot];
-  return (p && p->exec) ? p : nullptr;
+  return (p && p->built) ? p : nullptr;
 }
 
 void evict_idle_plans(piper_hip_voice* v) {
   auto total = [&]() { size_t b = 0; for (auto& p : v->plans) b += p->arena_bytes; return b; };
-  while (v->plans.size() > kPlanCacheMax || total() > kPlanCacheBytes) {
+  while (v->plans.size() > v->plan_cache_max || total() > v->plan_cache_bytes) {
     int victim = -1;
     for (int i = 0; i < (int)v->plans.size(); i++)
       if (!v->plans[i]->in_use && (victim < 0 || v->plans[i]->last_use < v->plans[victim]->last_use)) victim = i;
@@ -1862,21 +1900,62 @@ void evict_idle_plans(piper_hip_voice* v) {
   }
 }
 
-// An idle plan for (kind, Tb, Fb, NB) at the voice's precision, built (schedule + eager validation pass + graph capture) if
+// Run a plan once on its stream. A plan that has a graph replays it; a freshly built one runs its schedule eagerly (the answer of
+// the request that missed the cache) and captures + instantiates the graph behind that run, so that the next request of the bucket
+// replays. The capture enqueues nothing; it and the instantiate are host work that overlaps the eager pass on the GPU.
+int launch_plan(piper_hip_voice* v, Slot& s) {
+  if (s.exec) {
+    PH_HIP(hipGraphLaunch(s.exec, s.stream), PIPER_HIP_ERR_LAUNCH);
+    return PIPER_HIP_OK;
+  }
+  int rc = run_schedule(s, s.stream, false);
+  if (rc) return rc;
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "plan: begin capture failed: %s", hipGetErrorString(e));
+  // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
+  // short kernels gain), so that graph stays a single chain unless asked otherwise. The bf16 generator's builder decides
+  // for itself (s.parallel).
+  rc = run_schedule(s, s.stream, s.parallel);
+  hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
+  if (rc) return rc;
+  if (ce != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "plan: graph capture failed: %s", hipGetErrorString(ce));
+  const auto t1 = clk::now();
+  ce = hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0);
+  if (ce != hipSuccess) { s.exec = nullptr; PH_FAIL(PIPER_HIP_ERR_LAUNCH, "plan: graph instantiate failed: %s", hipGetErrorString(ce)); }
+  v->last_build_ms[4] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  v->last_build_ms[5] = std::chrono::duration<double, std::milli>(clk::now() - t1).count();
+  return PIPER_HIP_OK;
+}
+
+// An idle plan for (kind, Tb, Fb, NB) at the voice's precision, built (schedule + arena; its graph follows its first run) if
 // the cache has none. *built reports whether this call paid for a build ("cold" prepare).
 int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** out, bool* built) {
   *built = false;
   for (auto& p : v->plans)
-    if (!p->in_use && p->exec && p->kind == kind && p->T == Tb && p->F == Fb && p->NB == NB && p->prec == v->precision) {
+    if (!p->in_use && p->built && p->kind == kind && p->T == Tb && p->F == Fb && p->NB == NB && p->prec == v->precision) {
+      const int rc0 = slot_init(v, *p);  // a plan that went idle gave its stream set back (detach)
+      if (rc0) return rc0;
       *out = p.get();
       return PIPER_HIP_OK;
     }
   std::unique_ptr<Slot> np(new Slot());
+  using clk = std::chrono::steady_clock;
+  auto t_prev = clk::now();
+  int phase = 0;
+  auto lap = [&]() {  // wall time of the build's phases → piper_hip_voice_last_build_breakdown
+    const auto now = clk::now();
+    if (phase < 6) v->last_build_ms[phase++] = std::chrono::duration<double, std::milli>(now - t_prev).count();
+    t_prev = now;
+  };
   int rc = slot_init(v, *np);
   if (rc) { slot_release(v, *np, true); return rc; }
+  lap();
   if ((rc = build_schedule(v, *np, Tb, Fb, NB, kind))) { slot_release(v, *np, true); return rc; }
+  lap();
   Slot& s = *np;
-  // the validation pass and the capture run on whatever the arena holds: give the length arrays legal values first
+  // a plan may be captured / profiled before every input has been uploaded: give the length arrays and index inputs legal values
   {
     std::vector<int> full((size_t)2 * NB);
     for (int b = 0; b < NB; b++) { full[b] = Tb; full[NB + b] = Fb; }
@@ -1887,35 +1966,16 @@ int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** ou
     if (e == hipSuccess && s.rng) e = hipMemsetAsync(s.rng, 0, (size_t)NB * 2 * sizeof(unsigned), s.stream);
     if (e == hipSuccess && s.dp_scalars) e = hipMemsetAsync(s.dp_scalars, 0, dp_scalars_bytes(NB), s.stream);
     if (e == hipSuccess && s.dp_noise) e = hipMemsetAsync(s.dp_noise, 0, (size_t)NB * 2 * Tb * sizeof(float), s.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);  // `full` is a local
     if (e != hipSuccess) { slot_release(v, s, true); PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: arena initialisation failed: %s", hipGetErrorString(e)); }
   }
-  // one eager pass validates every launch (and sets kernel attributes) before capture
-  if ((rc = run_schedule(s, s.stream, false))) { slot_release(v, s, true); return rc; }
-  hipError_t e = hipStreamSynchronize(s.stream);
-  if (e != hipSuccess) {
-    slot_release(v, s, true);
-    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: eager pass failed: %s", hipGetErrorString(e));
-  }
-  if ((e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) {
-    slot_release(v, s, true);
-    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: begin capture failed: %s", hipGetErrorString(e));
-  }
-  // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
-  // short kernels gain), so that graph stays a single chain unless asked otherwise. The bf16 generator's builder decides
-  // for itself (s.parallel).
-  rc = run_schedule(s, s.stream, s.parallel);
-  hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
-  if (rc || ce != hipSuccess) {
-    slot_release(v, s, true);
-    if (rc) return rc;
-    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph capture failed: %s", hipGetErrorString(ce));
-  }
-  ce = hipGraphInstantiate(&s.exec, s.graph, nullptr, nullptr, 0);
-  if (ce != hipSuccess) {
-    slot_release(v, s, true);
-    PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: graph instantiate failed: %s", hipGetErrorString(ce));
-  }
+  lap();
+  // No validation pass and no capture here (until round 3 a build ran the schedule once eagerly, waited for it, captured it and
+  // instantiated the graph before the caller's inputs were even uploaded: 1–6 ms of GPU time + 0.3 ms on the critical path of the
+  // first request of a bucket). The plan's FIRST launch goes out eagerly — that run IS the request's answer — and the graph is
+  // captured and instantiated right behind it, host work that overlaps the GPU's (launch_plan).
+  s.built = true;
+  lap(); lap(); lap();
   *out = np.get();
   v->plans.push_back(std::move(np));
   *built = true;
@@ -1929,6 +1989,13 @@ void detach(piper_hip_voice* v, int slot) {
   p->in_use = false;
   p->st_next = -1;
   v->attached[slot] = nullptr;
+  // An idle plan needs no stream: hand the set to the next plan that is attached (usually the one replacing this plan on the same
+  // slot id), so that after a slot id's first request no prepare ever creates a stream again (≈ 3 ms each, r3).
+  if (p->inited && p->stream) {
+    v->free_sets.push_back({p->stream, {p->side[0], p->side[1]}, p->ev0, p->ev1, p->ev_fork, {p->ev_join[0], p->ev_join[1]}});
+    p->stream = nullptr; p->side[0] = p->side[1] = nullptr; p->ev0 = p->ev1 = p->ev_fork = nullptr; p->ev_join[0] = p->ev_join[1] = nullptr;
+    p->inited = false;
+  }
 }
 
 }  // namespace
@@ -1994,7 +2061,7 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   Slot* cur = v->attached[slot];
   const int kind = (dp_plan && dp_plan->stats && dp_plan->T == T && dp_plan->NB == n) ? 3 : 0;
-  const bool same = cur && cur->exec && cur->kind == kind && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
+  const bool same = cur && cur->built && cur->kind == kind && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
   if (cur && !same) detach(v, slot);
   if (!same) {
     bool built = false;
@@ -2019,20 +2086,31 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   s.st_next = -1;
   s.h_T = hT;
   s.h_F = hF;
-  if (s.h_cap_t < (size_t)T * n) {
-    if (s.h_ids) (void)hipHostFree(s.h_ids);
-    PH_HIP(hipHostMalloc((void**)&s.h_ids, (size_t)T * n * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
-    s.h_cap_t = (size_t)T * n;
-  }
-  if (s.h_cap_f < (size_t)F * n) {
-    if (s.h_f2i) (void)hipHostFree(s.h_f2i);
-    PH_HIP(hipHostMalloc((void**)&s.h_f2i, (size_t)F * n * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
-    s.h_cap_f = (size_t)F * n;
-  }
-  if (s.h_cap_lens < (size_t)2 * n) {
-    if (s.h_lens) (void)hipHostFree(s.h_lens);
-    PH_HIP(hipHostMalloc((void**)&s.h_lens, (size_t)2 * n * sizeof(int)), PIPER_HIP_ERR_ALLOC);
-    s.h_cap_lens = (size_t)2 * n;
+  {
+    auto& sg = v->staging[slot];
+    auto grow = [](size_t need) { size_t c = 1024; while (c < need) c <<= 1; return c; };
+    if (sg.cap_t < (size_t)T * n) {
+      if (sg.h_ids) (void)hipHostFree(sg.h_ids);
+      sg.h_ids = nullptr; sg.cap_t = 0;
+      const size_t c = grow((size_t)T * n);
+      PH_HIP(hipHostMalloc((void**)&sg.h_ids, c * sizeof(int64_t)), PIPER_HIP_ERR_ALLOC);
+      sg.cap_t = c;
+    }
+    if (sg.cap_f < (size_t)F * n) {
+      if (sg.h_f2i) (void)hipHostFree(sg.h_f2i);
+      sg.h_f2i = nullptr; sg.cap_f = 0;
+      const size_t c = grow((size_t)F * n);
+      PH_HIP(hipHostMalloc((void**)&sg.h_f2i, c * sizeof(int32_t)), PIPER_HIP_ERR_ALLOC);
+      sg.cap_f = c;
+    }
+    if (sg.cap_lens < (size_t)2 * n) {
+      if (sg.h_lens) (void)hipHostFree(sg.h_lens);
+      sg.h_lens = nullptr; sg.cap_lens = 0;
+      const size_t c = grow((size_t)2 * n);
+      PH_HIP(hipHostMalloc((void**)&sg.h_lens, c * sizeof(int)), PIPER_HIP_ERR_ALLOC);
+      sg.cap_lens = c;
+    }
+    s.h_ids = sg.h_ids; s.h_f2i = sg.h_f2i; s.h_lens = sg.h_lens;  // borrowed for this request (the plan's stream was synchronised above)
   }
   s.h_noise_scale.resize(n);
   s.h_rng.resize(2 * (size_t)n);
@@ -2123,7 +2201,7 @@ int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int
   if (e == hipSuccess) e = hipMemcpyAsync(s.lensT, lens.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream);
   if (e == hipSuccess) e = hipMemcpyAsync(s.dp_noise, nz.data(), nz.size() * sizeof(float), hipMemcpyHostToDevice, s.stream);
   if (e == hipSuccess) e = hipMemcpyAsync(s.dp_scalars, sc.data(), sc.size(), hipMemcpyHostToDevice, s.stream);
-  if (e == hipSuccess) e = hipGraphLaunch(s.exec, s.stream);
+  if (e == hipSuccess && launch_plan(v, s)) e = hipErrorUnknown;
   std::vector<int32_t> dur((size_t)n * T);
   std::vector<float> lw(logw_out ? (size_t)n * T : 0);
   if (e == hipSuccess) e = hipMemcpyAsync(dur.data(), s.dp_dur, dur.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
@@ -2176,6 +2254,20 @@ PH_EXPORT int piper_hip_voice_batch_size(const piper_hip_voice* v, int slot) {
   return p ? p->NB : 0;
 }
 
+PH_EXPORT int piper_hip_voice_set_plan_cache(piper_hip_voice* v, int max_plans, size_t max_bytes) {
+  if (!v || max_plans < 1) PH_FAIL(PIPER_HIP_ERR_ARG, "set_plan_cache: need a voice and max_plans >= 1");
+  v->plan_cache_max = (size_t)max_plans;
+  v->plan_cache_bytes = max_bytes ? max_bytes : kPlanCacheBytes;
+  evict_idle_plans(v);
+  return PIPER_HIP_OK;
+}
+
+PH_EXPORT int piper_hip_voice_last_build_breakdown(const piper_hip_voice* v, double out_ms[6]) {
+  if (!v || !out_ms) PH_FAIL(PIPER_HIP_ERR_ARG, "last_build_breakdown: null argument");
+  for (int i = 0; i < 6; i++) out_ms[i] = v->last_build_ms[i];
+  return PIPER_HIP_OK;
+}
+
 PH_EXPORT int piper_hip_voice_plan_info(const piper_hip_voice* v, int slot, int32_t* bucket_t_out, int32_t* bucket_f_out, int32_t* cached_plans,
                                         size_t* cached_bytes) {
   if (!v) PH_FAIL(PIPER_HIP_ERR_ARG, "null voice");
@@ -2212,7 +2304,10 @@ PH_EXPORT int piper_hip_voice_launch(piper_hip_voice* v, int slot) {
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   Slot& s = *p;
   PH_HIP(hipEventRecord(s.ev0, s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipGraphLaunch(s.exec, s.stream), PIPER_HIP_ERR_LAUNCH);
+  {
+    const int lrc = launch_plan(v, s);
+    if (lrc) return lrc;
+  }
   PH_HIP(hipEventRecord(s.ev1, s.stream), PIPER_HIP_ERR_LAUNCH);
   s.timed = true;
   return PIPER_HIP_OK;
@@ -2241,11 +2336,17 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
       if (hipPointerGetAttributes(&at, host_audio) == hipSuccess) caller_pinned = at.type == hipMemoryTypeHost;
       else (void)hipGetLastError();
     }
-    if (!caller_pinned && bytes <= kPinnedMax && s.h_audio_cap < bytes) {
-      if (s.h_audio) (void)hipHostFree(s.h_audio);
-      s.h_audio = nullptr; s.h_audio_cap = 0;
-      if (hipHostMalloc((void**)&s.h_audio, bytes) == hipSuccess) s.h_audio_cap = bytes;
-      else { s.h_audio = nullptr; (void)hipGetLastError(); }
+    {
+      auto& sg = v->staging[slot];
+      if (!caller_pinned && bytes <= kPinnedMax && sg.audio_cap < bytes) {
+        if (sg.h_audio) (void)hipHostFree(sg.h_audio);
+        sg.h_audio = nullptr; sg.audio_cap = 0;
+        size_t c = 65536;
+        while (c < bytes) c <<= 1;
+        if (hipHostMalloc((void**)&sg.h_audio, c) == hipSuccess) sg.audio_cap = c;
+        else { sg.h_audio = nullptr; (void)hipGetLastError(); }
+      }
+      s.h_audio = sg.audio_cap >= bytes ? sg.h_audio : nullptr;
     }
     float* dst = (!caller_pinned && bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
     // Short waveforms into page-locked memory are written by a KERNEL through the host mapping instead of the copy engine: the
@@ -2380,7 +2481,7 @@ PH_EXPORT int piper_hip_voice_stream_next(piper_hip_voice* v, int slot, float* h
   if (e == hipSuccess)
     e = hipMemcpy2DAsync(gs->zin, (size_t)gs->F * sizeof(float), s.z_out + a, (size_t)s.F * sizeof(float), (size_t)Fc * sizeof(float), (size_t)I,
                          hipMemcpyDeviceToDevice, gs->stream);
-  if (e == hipSuccess) e = hipGraphLaunch(gs->exec, gs->stream);
+  if (e == hipSuccess && launch_plan(v, *gs)) e = hipErrorUnknown;
   if (e == hipSuccess && host_audio)
     e = hipMemcpyAsync(host_audio, gs->audio + (int64_t)(f0 - a) * v->hop, (size_t)want * sizeof(float), hipMemcpyDeviceToHost, gs->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(gs->stream);

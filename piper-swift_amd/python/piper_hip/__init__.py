@@ -185,6 +185,8 @@ _PROTOS = {
     "piper_hip_onnx_build_blob": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
     "piper_hip_onnx_build_blob_unchecked": (C.c_int, [c_vp, C.POINTER(VoiceConfig), c_f32p, C.c_size_t]),
     "piper_hip_onnx_verify_graph": (C.c_int, [c_vp, C.POINTER(VoiceConfig)]),
+    "piper_hip_voice_last_build_breakdown": (C.c_int, [c_vp, C.POINTER(C.c_double)]),
+    "piper_hip_voice_set_plan_cache": (C.c_int, [c_vp, C.c_int, C.c_size_t]),
     "piper_hip_piper_json": (C.c_int, [C.c_char_p, C.POINTER(PiperJsonInfo)]),
     "piper_hip_voice_check_json": (C.c_int, [C.POINTER(VoiceConfig), C.POINTER(PiperJsonInfo)]),
     "piper_hip_pcm16_from_f32": (C.c_int, [c_f32p, C.c_size_t, C.POINTER(C.c_int16)]),
@@ -896,6 +898,15 @@ class HipRuntime:
         bt, bf, n, by = C.c_int32(), C.c_int32(), C.c_int32(), C.c_size_t()
         _check(self.lib.piper_hip_voice_plan_info(self.voice, slot, C.byref(bt), C.byref(bf), C.byref(n), C.byref(by)))
         return dict(bucket_t=bt.value, bucket_f=bf.value, cached_plans=n.value, cached_bytes=by.value)
+
+    def set_plan_cache(self, max_plans, max_bytes=0):
+        _check(self.lib.piper_hip_voice_set_plan_cache(self.voice, int(max_plans), int(max_bytes)))
+
+    def last_build_breakdown(self):
+        """ms of the phases of the latest plan build (cold prepare): streams, schedule + arena, arena init, eager pass, capture, instantiate."""
+        a = (C.c_double * 6)()
+        _check(self.lib.piper_hip_voice_last_build_breakdown(self.voice, a))
+        return dict(zip(("streams_events", "schedule_and_arena", "arena_init", "eager_pass", "capture", "instantiate"), (round(x, 3) for x in a)))
 
     def launch(self, slot):
         _check(self.lib.piper_hip_voice_launch(self.voice, slot))
