@@ -19,30 +19,39 @@ namespace ph {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kW = 8;          // waves per block
-constexpr int kNT = 64 * kW;   // threads
-constexpr int kMaxRows = 8;    // channel rows per thread in the depthwise phase: H ≤ 256
-constexpr int kMaxTiles = 2;   // 16-row tiles per wave in the pointwise phase: H ≤ 256
 constexpr int kMaxBins = 16;
 
-__device__ __forceinline__ float gelu_erf(float v) {  // the graph's Div(√2) → Erf → Add(1) → Mul(x) → Mul(0.5)
-  const float e = erff(v / 1.4142135381698608f);
+// the graph's Div(√2) → Erf → Add(1) → Mul(x) → Mul(0.5). r3: x·(1/√2) instead of the correctly rounded division (≈ 10 vector
+// instructions each; a wave of dds_layer_kernel issued ≈ 2 000 of them and the launch is bound by exactly that — PMC SQ_INSTS_VALU):
+// one rounding step (≤ 1 ulp) from the graph's value.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float e = erff(v * 0.70710678118654752f);
   return (v * (e + 1.0f)) * 0.5f;
 }
 
 // x, out: [N][H][T]. dw_w [H][KD], dw_b [H]; pw16: packed 16-wide fragment image of the 1×1 conv (pack_conv_weights tm = 16),
 // pw_steps its padded step count; g1/b1, g2/b2: LayerNorm parameters. Tv = true length (columns ≥ Tv read as zero, are not
 // written).
-template <int KD>
-__global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
+// FAST: H % 64 == 0 and an unpadded fragment image (pw_steps = H / 4): no clamps / selects in the K loop.
+// kW waves per block. kW = 12 (H ≤ 192: one 16-row tile of the pointwise conv per wave) is the PREFETCH variant: a wave requests its
+// tile's whole weight slab (H / 4 ≤ 48 fragments) and the epilogue's operands at kernel start, before the depthwise phase, so that the
+// pointwise phase never waits for memory — with batches of 16 fragments fetched one batch ahead, each batch's ≈ 1 µs cold round trip
+// stood behind 0.25 µs of MFMAs (r3: the launch is a chain of such waits, not vector-ALU work: halving the instruction count moved nothing).
+template <int KD, bool FAST, int kW>
+__global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                        const float* __restrict__ dw_b, const float* __restrict__ g1,
                                                        const float* __restrict__ b1, const float* __restrict__ pw16,
                                                        const float* __restrict__ pw_b, const float* __restrict__ g2,
                                                        const float* __restrict__ b2, float* __restrict__ out, int H, int T, int dil,
                                                        int pw_steps, const int* __restrict__ len_ptr, float eps) {
+  constexpr int kNT = 64 * kW;
+  constexpr int kRP = kNT / 16;                       // channel rows per pass of the depthwise phase
+  constexpr int kMaxRows = (256 + kRP - 1) / kRP;     // passes: H ≤ 256
+  constexpr int kMaxTiles = (16 + kW - 1) / kW;       // 16-row tiles per wave in the pointwise phase
+  constexpr bool PRE = FAST && kW == 12;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* act = sm;             // [H][16]   B operand of the pointwise conv
-  float* red = act + H * 16;   // [32][16]  column partials
+  float* red = act + H * 16;   // [kRP][16] column partials
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y, t0 = blockIdx.x * 16;
@@ -50,8 +59,26 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   if (t0 >= Tv) return;
   const float* xb = x + (int64_t)n * H * T;
   float* ob = out + (int64_t)n * H * T;
+  // PRE: this wave's weight slab, bias, LayerNorm-2 operands and residual, all requested before anything else
+  float apre[PRE ? 48 : 1], pbias[4], pg2[4], pb2[4], pxr[4];
+  if constexpr (PRE) {
+    const int mtc = min(wave, ((H + 15) >> 4) - 1);  // one tile per wave (≤ 12 tiles)
+    const float* wa0 = pw16 + (int64_t)mtc * pw_steps * 64 + lane;
+    const int nst0 = H >> 2;
+#pragma unroll
+    for (int u = 0; u < 48; u++) apre[u] = wa0[min(u, nst0 - 1) * 64];
+    const int tc0 = min(t0 + (lane & 15), T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = min(16 * mtc + 4 * (lane >> 4) + r, H - 1);
+      pbias[r] = pw_b[c];
+      pg2[r] = g2[c];
+      pb2[r] = b2[c];
+      pxr[r] = xb[(int64_t)c * T + tc0];
+    }
+  }
   // ---- 1. depthwise conv: thread ↔ (channel c = tid / 16 + 32·i, column tid % 16)
-  const int col = tid & 15, crow = tid >> 4;  // 32 channel rows per pass
+  const int col = tid & 15, crow = tid >> 4;  // kRP channel rows per pass
   const int t = t0 + col;
   float y[kMaxRows];
   float s1 = 0.0f;
@@ -60,7 +87,7 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   float xv[kMaxRows][KD], wv[kMaxRows][KD], bv[kMaxRows], g1v[kMaxRows], b1v[kMaxRows];
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
-    const int c = min(crow + 32 * i, H - 1);
+    const int c = min(crow + kRP * i, H - 1);
     bv[i] = dw_b[c];
     g1v[i] = g1[c];
     b1v[i] = b1[c];
@@ -73,7 +100,7 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
-    const int c = crow + 32 * i;
+    const int c = crow + kRP * i;
     float acc = bv[i];  // bias first, then the taps in order (CPUBackend.conv1d with Cin/g = 1)
 #pragma unroll
     for (int k = 0; k < KD; k++) {
@@ -88,13 +115,13 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   __syncthreads();
   float mean = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 32; q++) mean += red[q * 16 + col];
+  for (int q = 0; q < kRP; q++) mean += red[q * 16 + col];
   mean = mean / (float)H;
   __syncthreads();
   float s2 = 0.0f;
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
-    const int c = crow + 32 * i;
+    const int c = crow + kRP * i;
     if (c < H) {
       y[i] -= mean;
       s2 += y[i] * y[i];
@@ -104,13 +131,13 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
   __syncthreads();
   float var = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 32; q++) var += red[q * 16 + col];
+  for (int q = 0; q < kRP; q++) var += red[q * 16 + col];
   var = var / (float)H;
-  const float sd = sqrtf(var + eps);
+  const float rsd = 1.0f / sqrtf(var + eps);  // one division per column instead of one per element (≤ 1 ulp from y / sd)
 #pragma unroll
   for (int i = 0; i < kMaxRows; i++) {
-    const int c = crow + 32 * i;
-    if (c < H) act[c * 16 + col] = gelu_erf((y[i] / sd) * g1v[i] + b1v[i]);
+    const int c = crow + kRP * i;
+    if (c < H) act[c * 16 + col] = gelu_erf((y[i] * rsd) * g1v[i] + b1v[i]);
   }
   __syncthreads();
   // ---- 3. pointwise conv on the tile: D[row = channel][col]; wave ↔ row tiles wave, wave + 8
@@ -126,10 +153,40 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
     for (int r = 0; r < 4; r++) val[ti][r] = 0.0f;
     if (mt < ntiles) {  // wave-uniform
       f32x4 acc;
+      if constexpr (PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = pbias[r];
+        const float* ab = act + kq * 16 + r16;
+#pragma unroll
+        for (int u = 0; u < 48; u++)
+          if (u < nst) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[u], ab[u * 64], acc, 0, 0, 0);  // wave-uniform bound
+      } else {
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[r] = pw_b[min(16 * mt + 4 * kq + r, H - 1)];
       const float* wa = pw16 + (int64_t)mt * pw_steps * 64 + lane;
       // weight fragments two batches of 16 steps ahead of the MFMAs that use them (the batches used to alternate load → wait → multiply)
+      if constexpr (FAST) {
+        // 16 steps per batch, the next batch's weight fragments in flight: plain immediate-offset loads, no per-step index arithmetic
+        const float* ab = act + kq * 16 + r16;
+        float a[2][16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) a[0][u] = wa[u * 64];
+        const int nb = nst >> 4;
+        for (int bt = 0; bt < nb; bt += 2) {
+#pragma unroll
+          for (int half = 0; half < 2; half++) {
+            const int sb = (bt + half) << 4;
+            if (bt + half < nb) {  // wave-uniform
+              const int nx = min(sb + 16, nst - 16);  // the last batch re-requests itself (unused)
+#pragma unroll
+              for (int u = 0; u < 16; u++) a[half ^ 1][u] = wa[(nx + u) * 64];
+              const float* abs_ = ab + sb * 64;
+#pragma unroll
+              for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[half][u], abs_[u * 64], acc, 0, 0, 0);
+            }
+          }
+        }
+      } else {
       float a[2][16];
 #pragma unroll
       for (int u = 0; u < 16; u++) a[0][u] = wa[min(u, pw_steps - 1) * 64];
@@ -146,6 +203,8 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
           for (int u = 0; u < 16; u++)
             if (sb + u < nst) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[half][u], 4 * (sb + u) + kq < H ? b[u] : 0.0f, acc, 0, 0, 0);
         }
+      }
+      }
       }
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -185,7 +244,7 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
 #pragma unroll
   for (int q = 0; q < kW; q++) var2 += red[q * 16 + r16];
   var2 = var2 / (float)H;
-  const float sd2 = sqrtf(var2 + eps);
+  const float rsd2 = 1.0f / sqrtf(var2 + eps);
   {
     const int tc = min(t0 + r16, T - 1);
     float g2v[kMaxTiles][4], b2v[kMaxTiles][4], xr[kMaxTiles][4];  // loads first (clamped), masked stores after
@@ -194,9 +253,13 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int c = min(16 * (wave + kW * ti) + 4 * kq + r, H - 1);
-        g2v[ti][r] = g2[c];
-        b2v[ti][r] = b2[c];
-        xr[ti][r] = xb[(int64_t)c * T + tc];
+        if constexpr (PRE) {
+          g2v[ti][r] = pg2[r]; b2v[ti][r] = pb2[r]; xr[ti][r] = pxr[r];
+        } else {
+          g2v[ti][r] = g2[c];
+          b2v[ti][r] = b2[c];
+          xr[ti][r] = xb[(int64_t)c * T + tc];
+        }
       }
 #pragma unroll
     for (int ti = 0; ti < kMaxTiles; ti++) {
@@ -204,7 +267,7 @@ __global__ __launch_bounds__(kNT) void dds_layer_kernel(const float* __restrict_
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int c = 16 * mt + 4 * kq + r;
-        const float hid = gelu_erf((val[ti][r] / sd2) * g2v[ti][r] + b2v[ti][r]);
+        const float hid = gelu_erf((val[ti][r] * rsd2) * g2v[ti][r] + b2v[ti][r]);
         if (t0 + r16 < Tv && mt < ntiles && c < H) ob[(int64_t)c * T + t0 + r16] = xr[ti][r] + hid;
       }
     }
@@ -237,54 +300,88 @@ __device__ __forceinline__ float softplus_ref(float v) { return v > 0.0f ? v + l
 
 // ConvFlow tail: z1 ← spline⁻¹(z1; h), then the Flip that precedes the next module, written in place as a row swap:
 // on exit row 0 = new z1, row 1 = z0. h [N][3·bins − 1][T].
+// NBM = compile-time bound of the bin count (10: every Piper voice; 16: the general case). Every operand of a column — the two latent
+// rows and all 3·nb − 1 spline parameters — is requested in ONE burst at kernel start (r3: the parameter loads used to sit behind the
+// latent's round trip and a range test, the two derivative loads behind the bin search — three dependent cold round trips, 11 µs per
+// launch for 2 waves of arithmetic); the bin's derivatives are then picked out of registers.
+template <int NBM>
 __global__ __launch_bounds__(256) void dp_spline_kernel(const float* __restrict__ h, float* __restrict__ z, int T, int nb, float B,
                                                        float filter_channels, const int* __restrict__ len_ptr) {
   const int n = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int Tv = len_ptr ? min(len_ptr[n], T) : T;
-  if (t >= Tv) return;
+  const int tc = min(t, T - 1);
   float* zb = z + (int64_t)n * 2 * T;
-  const float* hb = h + (int64_t)n * (3 * nb - 1) * T + t;
-  const float z0 = zb[t], x = zb[T + t];
+  const float* hb = h + (int64_t)n * (3 * nb - 1) * T + tc;
+  const float z0 = zb[tc], x = zb[T + tc];
+  float hw[NBM], hh[NBM], hd[NBM];  // widths, heights, derivatives (nb − 1 of them)
+#pragma unroll
+  for (int i = 0; i < NBM; i++) {
+    const int ic = min(i, nb - 1);
+    hw[i] = hb[(int64_t)ic * T];
+    hh[i] = hb[(int64_t)(nb + ic) * T];
+    hd[i] = hb[(int64_t)(2 * nb + min(i, nb - 2)) * T];
+  }
+  if (t >= Tv) return;
   float outv = x;
   if (x >= -B && x <= B) {
     const float mbw = 1e-3f, mbh = 1e-3f, md = 1e-3f;
     const float inv = sqrtf(filter_channels);
-    float w[kMaxBins], hh[kMaxBins], cw[kMaxBins + 1], ch[kMaxBins + 1];
+    float w[NBM], cw[NBM + 1], ch[NBM + 1];
     float mw = -INFINITY, mh = -INFINITY;
-    for (int i = 0; i < nb; i++) {
-      w[i] = hb[(int64_t)i * T] / inv;
-      hh[i] = hb[(int64_t)(nb + i) * T] / inv;
-      mw = fmaxf(mw, w[i]);
-      mh = fmaxf(mh, hh[i]);
-    }
+#pragma unroll
+    for (int i = 0; i < NBM; i++)
+      if (i < nb) {
+        w[i] = hw[i] / inv;
+        hh[i] = hh[i] / inv;
+        mw = fmaxf(mw, w[i]);
+        mh = fmaxf(mh, hh[i]);
+      }
     float sw = 0.0f, sh = 0.0f;
-    for (int i = 0; i < nb; i++) { w[i] = expf(w[i] - mw); sw += w[i]; hh[i] = expf(hh[i] - mh); sh += hh[i]; }
+#pragma unroll
+    for (int i = 0; i < NBM; i++)
+      if (i < nb) { w[i] = expf(w[i] - mw); sw += w[i]; hh[i] = expf(hh[i] - mh); sh += hh[i]; }
     const float isw = 1.0f / sw, ish = 1.0f / sh;  // softmax.metal: multiply by 1/sum
     cw[0] = 0.0f; ch[0] = 0.0f;
-    for (int i = 0; i < nb; i++) {
-      cw[i + 1] = cw[i] + (mbw + (1.0f - mbw * nb) * (w[i] * isw));
-      ch[i + 1] = ch[i] + (mbh + (1.0f - mbh * nb) * (hh[i] * ish));
-    }
-    for (int i = 0; i <= nb; i++) { cw[i] = (2.0f * B) * cw[i] + -B; ch[i] = (2.0f * B) * ch[i] + -B; }
-    cw[0] = -B; cw[nb] = B; ch[0] = -B; ch[nb] = B;
+#pragma unroll
+    for (int i = 0; i < NBM; i++)
+      if (i < nb) {
+        cw[i + 1] = cw[i] + (mbw + (1.0f - mbw * nb) * (w[i] * isw));
+        ch[i + 1] = ch[i] + (mbh + (1.0f - mbh * nb) * (hh[i] * ish));
+      }
+#pragma unroll
+    for (int i = 0; i <= NBM; i++)
+      if (i <= nb) { cw[i] = (2.0f * B) * cw[i] + -B; ch[i] = (2.0f * B) * ch[i] + -B; }
     int idx = -1;  // Σ (x ≥ location) − 1, the last location nudged by 1e-6
-    for (int i = 0; i <= nb; i++) idx += (x >= (i == nb ? ch[i] + 1e-6f : ch[i])) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i <= NBM; i++)
+      if (i <= nb) {
+        if (i == 0) { cw[i] = -B; ch[i] = -B; }
+        if (i == nb) { cw[i] = B; ch[i] = B; }
+        idx += (x >= (i == nb ? ch[i] + 1e-6f : ch[i])) ? 1 : 0;
+      }
     idx = min(max(idx, 0), nb - 1);
     const float cdv = softplus_ref(logf(expf(1.0f - md) - 1.0f));
-    const float d0 = md + (idx == 0 ? cdv : softplus_ref(hb[(int64_t)(2 * nb + idx - 1) * T]));
-    const float d1 = md + (idx == nb - 1 ? cdv : softplus_ref(hb[(int64_t)(2 * nb + idx) * T]));
-    const float ibw = cw[idx + 1] - cw[idx], ih = ch[idx + 1] - ch[idx];
+    // derivative rows idx − 1 and idx, the bin's edges: picked out of the registers loaded above
+    float dl = 0.0f, dr = 0.0f, cwl = 0.0f, cwr = 0.0f, chl = 0.0f, chr_ = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NBM; i++) {
+      if (i == idx - 1) dl = hd[i];
+      if (i == idx) { dr = hd[i]; cwl = cw[i]; cwr = cw[i + 1]; chl = ch[i]; chr_ = ch[i + 1]; }
+    }
+    const float d0 = md + (idx == 0 ? cdv : softplus_ref(dl));
+    const float d1 = md + (idx == nb - 1 ? cdv : softplus_ref(dr));
+    const float ibw = cwr - cwl, ih = chr_ - chl;
     const float idl = ih / ibw;
     const float i1 = d0 + d1 - 2.0f * idl;
-    const float i2 = x - ch[idx];
+    const float i2 = x - chl;
     const float i3 = i2 * i1;
     const float a = ih * (idl - d0) + i3;
     const float b = ih * d0 - i3;
     const float cc = -idl * i2;
     const float disc = b * b - 4.0f * a * cc;
     const float root = (2.0f * cc) / (-b - sqrtf(disc));
-    outv = root * ibw + cw[idx];
+    outv = root * ibw + cwl;
   }
   zb[t] = outv;    // Flip: the transformed half becomes row 0 …
   zb[T + t] = z0;  // … and the untouched half row 1
@@ -327,8 +424,17 @@ int launch_dds_layer(piper_hip_ctx* ctx, hipStream_t s, const float* x, const fl
   if (N <= 0 || T <= 0) return PIPER_HIP_OK;
   if (!dds_layer_eligible(H, K) || N > 65535) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "dds_layer: H=%d K=%d not covered", H, K);
   const dim3 grid((unsigned)ceil_div(T, 16), (unsigned)N);
-  const size_t lds = ((size_t)H * 16 + 32 * 16) * sizeof(float);
-#define PH_DDS(KK) hipLaunchKernelGGL(dds_layer_kernel<KK>, grid, dim3(kNT), lds, s, x, dw_w, dw_b, g1, b1, pw16, pw_b, g2, b2, out, H, T, dil, pw_steps, len_ptr, eps)
+  const bool fast = (H % 64) == 0 && pw_steps == H / 4;
+  static const bool no_pre = getenv("PIPER_HIP_DDS_NO_PREFETCH") != nullptr;
+  const bool pre = fast && H <= 192 && !no_pre;  // ≤ 12 row tiles: one per wave of a 768-thread block, weight slab prefetched
+  const size_t lds = ((size_t)H * 16 + (pre ? 48 : 32) * 16) * sizeof(float);
+#define PH_DDS_ARGS(NW_) grid, dim3(64 * NW_), lds, s, x, dw_w, dw_b, g1, b1, pw16, pw_b, g2, b2, out, H, T, dil, pw_steps, len_ptr, eps
+#define PH_DDS(KK)                                                                             \
+  do {                                                                                         \
+    if (pre) hipLaunchKernelGGL((dds_layer_kernel<KK, true, 12>), PH_DDS_ARGS(12));            \
+    else if (fast) hipLaunchKernelGGL((dds_layer_kernel<KK, true, 8>), PH_DDS_ARGS(8));        \
+    else hipLaunchKernelGGL((dds_layer_kernel<KK, false, 8>), PH_DDS_ARGS(8));                 \
+  } while (0)
   switch (K) {
     case 1: PH_DDS(1); break;
     case 3: PH_DDS(3); break;
@@ -336,6 +442,7 @@ int launch_dds_layer(piper_hip_ctx* ctx, hipStream_t s, const float* x, const fl
     default: PH_DDS(7); break;
   }
 #undef PH_DDS
+#undef PH_DDS_ARGS
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "dds_layer launch failed: %s", hipGetErrorString(e));
   return PIPER_HIP_OK;
@@ -347,9 +454,10 @@ int launch_dp_init(hipStream_t s, const float* noise, const void* scalars, float
   return PIPER_HIP_OK;
 }
 int launch_dp_spline(hipStream_t s, const float* h, float* z, int N, int T, int bins, float tail_bound, float filter_channels, const int* len_ptr) {
-  if (bins > kMaxBins) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "dp spline: %d bins (max %d)", bins, kMaxBins);
-  const dim3 grid((unsigned)ceil_div(T, 256), (unsigned)N);
-  hipLaunchKernelGGL(dp_spline_kernel, grid, dim3(256), 0, s, h, z, T, bins, tail_bound, filter_channels, len_ptr);
+  if (bins > kMaxBins || bins < 2) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "dp spline: %d bins (2 … %d)", bins, kMaxBins);
+  const dim3 grid((unsigned)ceil_div(T, 64), (unsigned)N);  // one-wave blocks: a column is one thread, and 112 of them should not share a CU
+  if (bins <= 10) hipLaunchKernelGGL(dp_spline_kernel<10>, grid, dim3(64), 0, s, h, z, T, bins, tail_bound, filter_channels, len_ptr);
+  else hipLaunchKernelGGL(dp_spline_kernel<kMaxBins>, grid, dim3(64), 0, s, h, z, T, bins, tail_bound, filter_channels, len_ptr);
   return PIPER_HIP_OK;
 }
 int launch_dp_final(hipStream_t s, const float* z, const float* m, const float* logs, const void* scalars, float* logw, int32_t* dur, int N, int T,

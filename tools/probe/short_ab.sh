@@ -22,7 +22,7 @@ rows=list(csv.DictReader(open(f[0])))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows:
     n=r["Name"]
-    if "conv_short" in n or "conv_stream" in n or "flow_seam" in n or "rel_att" in n:
+    if float(r["TotalDurationNs"]) > 0.004 * tot:
         n=re.sub(r"void ph::detail::|\(ph::ConvArgs.*","",n)
         print("  %-60s calls %5s avg %7.2f us  %5.1f%%"%(n[:60], r["Calls"], float(r["AverageNs"])/1e3, 100*float(r["TotalDurationNs"])/tot))
 PY
