@@ -394,7 +394,8 @@ typedef struct {
   int32_t t;
   const int32_t* durations; /* [T] host, frames per id (≥0), F = Σ durations — the `overrides` route; NULL: predicted on the device
                                by the voice's stochastic duration predictor from length_scale / noise_w / dp_noise (ABI 2) */
-  const float* noise;       /* `main` RandomNormalLike [inter, F] host, may be NULL (see noise_mode) */
+  const float* noise;       /* `main` RandomNormalLike [inter, F] host, may be NULL (see noise_mode). Must be NULL when durations is NULL
+                               (F is not known to the caller then: PIPER_HIP_ERR_ARG; predict_durations first, or noise_mode DEVICE) */
   float noise_scale;        /* scales[0] */
   /* ---- ABI 2 ---- */
   int32_t noise_mode;       /* PIPER_HIP_NOISE_INJECTED / PIPER_HIP_NOISE_DEVICE */

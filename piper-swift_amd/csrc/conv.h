@@ -66,11 +66,12 @@ struct ConvArgs {
   int len_mul = 1;
   // LayerNorm across a kernel boundary without a kernel of its own (GraphExecutor.swift:2071-2125: ReduceMean / Sub / Pow /
   // ReduceMean / Add / Sqrt / Div / Mul / Add). PRODUCER (EPI_STORE with stats_out): besides y = res + conv it writes, per
-  // 16-row slot and column, the partial sums Σ y and Σ y² of its rows → stats_out [N][ceil(Cout/16)][y_len][2] (32-row tiles
-  // fill the even slot and zero the odd one, so the consumer never needs to know the producer's tile size; fixed slots ⇒
-  // deterministic). CONSUMER (PRO_LN): adds the slots of a column in order, mean = Σ/C, var = Σ²/C − mean² (≥ 0), and
-  // normalises its B operand on load; the waves of row tile 0 also write the normalised tensor to ln_out (the residual
-  // operand of the next Add, and the "enc_out" tap).
+  // 16-row slot and column, Σ y and the CENTRED Σ (y − mean_slot)² of its rows → stats_out [N][ceil(Cout/16)][y_len][2] (a 32-row
+  // tile writes its two slots, so the consumer never needs to know the producer's tile size; fixed slots ⇒ deterministic).
+  // CONSUMER (PRO_LN): combines the slots of a column with Chan's parallel-variance formula — mean = ΣΣ / C, M2 = Σ [M2_i +
+  // n_i·(mean_i − mean)²], var = M2 / C: the two-pass accuracy of the graph's chain in one memory round trip (r3; the one-pass
+  // Σ y² / C − mean² of round 2 lost (mean / sigma)²·6e-8) — and normalises its B operand on load; the waves of row tile 0 also
+  // write the normalised tensor to ln_out (the residual operand of the next Add, and the "enc_out" tap).
   float* stats_out = nullptr;
   const float* ln_stats = nullptr;
   const float* ln_gamma = nullptr;

@@ -322,20 +322,27 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
               pr[q] = *(const float2*)(sb + ((int64_t)min(slot, parts - 1) * p.Lin + col) * 2);
               if (slot >= parts) pr[q] = make_float2(0.0f, 0.0f);
             }
-            float s1 = 0.0f, s2 = 0.0f;
+            // slot i holds (Σ y, Σ (y − mean_i)²) of its n_i rows: Chan's combination — mean = ΣΣ / C, M2 = Σ [M2_i + n_i·(mean_i − mean)²] —
+            // instead of Σ y² / C − mean², which loses (mean / sigma)² · 6e-8 of relative accuracy
+            float s1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < PPG; q++) s1 += pr[q].x;
+            s1 += __shfl_xor(s1, 32, 64);
+            if constexpr (NG == 4) s1 += __shfl_xor(s1, 16, 64);
+            const float mean = s1 / (float)p.Cin;
+            float m2 = 0.0f;
 #pragma unroll
             for (int q = 0; q < PPG; q++) {
-              s1 += pr[q].x;
-              s2 += pr[q].y;
+              const int slot = kk * PPG + q;
+              const float ni = (float)min(16, p.Cin - 16 * slot);
+              if (slot < parts) {
+                const float dm = pr[q].x / ni - mean;
+                m2 += pr[q].y + ni * (dm * dm);
+              }
             }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if constexpr (NG == 4) {
-              s1 += __shfl_xor(s1, 16, 64);
-              s2 += __shfl_xor(s2, 16, 64);
-            }
-            const float mean = s1 / (float)p.Cin;
-            const float var = fmaxf(s2 / (float)p.Cin - mean * mean, 0.0f);
+            m2 += __shfl_xor(m2, 32, 64);
+            if constexpr (NG == 4) m2 += __shfl_xor(m2, 16, 64);
+            const float var = m2 / (float)p.Cin;
             lnm[k][nt] = mean;
             lns[k][nt] = 1.0f / sqrtf(var + p.ln_eps);  // reciprocal once per column: a division per operand element in the K loop is ≈ 10 vector instructions next to every MFMA
           }
@@ -462,35 +469,43 @@ __global__ __launch_bounds__(BT) void conv_stream_kernel(const ConvArgs p, const
       EpiIn e[NR];
 #pragma unroll
       for (int r = 0; r < NR; r++) e[r] = epi_load<MODE>(p, n, min(mt * TM + acc_row_t<TM>(r, lane), rows_out - 1), colc);
-      float ps1 = 0.0f, ps2 = 0.0f;
+      float vals[NR];
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         const int row = mt * TM + acc_row_t<TM>(r, lane);
         float v = acc[0][nt][r];
         if constexpr (GATE) v = tanhf(v) * sigmoid_stable(acc[1][nt][r]);
+        vals[r] = 0.0f;
         if (col < p.Lout && row < rows_out) {
           epi_finish<MODE>(p, n, row, col, v, e[r]);
-          if constexpr (MODE == EPI_STORE) {
-            const float val = p.res ? v + e[r].a : v;  // exactly what epi_finish stored
-            ps1 += val;
-            ps2 += val * val;
-          }
+          if constexpr (MODE == EPI_STORE) vals[r] = p.res ? v + e[r].a : v;  // exactly what epi_finish stored
         }
       }
       if constexpr (MODE == EPI_STORE && !GATE) {
-        if (p.stats_out) {  // wave-uniform: partial LayerNorm sums of this tile's rows per column (see ConvArgs)
-          ps1 += __shfl_xor(ps1, 32, 64);
-          ps2 += __shfl_xor(ps2, 32, 64);
-          if constexpr (TM == 16) {
-            ps1 += __shfl_xor(ps1, 16, 64);
-            ps2 += __shfl_xor(ps2, 16, 64);
-          }
-          if (lane < TM && col < p.Lout) {
-            const int parts = (p.Cout + 15) >> 4;
-            float* sb = p.stats_out + (int64_t)n * parts * p.y_len * 2;
-            const int slot = TM == 16 ? mt : 2 * mt;
-            *(float2*)(sb + ((int64_t)slot * p.y_len + col) * 2) = make_float2(ps1, ps2);
-            if (TM == 32 && slot + 1 < parts) *(float2*)(sb + ((int64_t)(slot + 1) * p.y_len + col) * 2) = make_float2(0.0f, 0.0f);
+        if (p.stats_out) {  // wave-uniform: LayerNorm statistics of this tile's rows per column and 16-row slot (see ConvArgs)
+          const int parts = (p.Cout + 15) >> 4;
+          float* sb = p.stats_out + (int64_t)n * parts * p.y_len * 2;
+          constexpr int NSL = TM / 16;  // 16-row slots of the tile: 32-wide tiles hold two (registers 0–7 / 8–15 of a lane)
+#pragma unroll
+          for (int sl = 0; sl < NSL; sl++) {
+            const int slot = NSL * mt + sl;
+            const float cnt = (float)max(1, min(16, rows_out - 16 * slot));
+            float s1 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR / NSL; r++) s1 += vals[sl * (NR / NSL) + r];
+            s1 += __shfl_xor(s1, 32, 64);
+            if constexpr (TM == 16) s1 += __shfl_xor(s1, 16, 64);
+            const float ms = s1 / cnt;
+            float q2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < NR / NSL; r++) {
+              const int row = mt * TM + acc_row_t<TM>(sl * (NR / NSL) + r, lane);
+              const float dv = vals[sl * (NR / NSL) + r] - ms;
+              if (row < rows_out) q2 += dv * dv;
+            }
+            q2 += __shfl_xor(q2, 32, 64);
+            if constexpr (TM == 16) q2 += __shfl_xor(q2, 16, 64);
+            if (lane < TM && col < p.Lout && slot < parts) *(float2*)(sb + ((int64_t)slot * p.y_len + col) * 2) = make_float2(s1, q2);
           }
         }
       }

@@ -147,14 +147,21 @@ __global__ __launch_bounds__(BT) void conv_short_kernel(const ConvArgs p, const 
             pr[q] = *(const float2*)(sb + ((int64_t)min(q, parts - 1) * Lin + col) * 2);
             if (q >= parts) pr[q] = make_float2(0.0f, 0.0f);
           }
-          float s1 = 0.0f, s2 = 0.0f;
+          // slot q holds (Σ y, Σ (y − mean_q)²) of its n_q rows: Chan's combination (see conv_kernels.hpp load_ln_stats)
+          float s1 = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 16; q++) s1 += pr[q].x;
+          const float mean = s1 / (float)Cin;
+          float m2 = 0.0f;
 #pragma unroll
           for (int q = 0; q < 16; q++) {
-            s1 += pr[q].x;
-            s2 += pr[q].y;
+            const float nq_ = (float)min(16, Cin - 16 * q);
+            if (q < parts) {
+              const float dm = pr[q].x / nq_ - mean;
+              m2 += pr[q].y + nq_ * (dm * dm);
+            }
           }
-          const float mean = s1 / (float)Cin;
-          const float var = fmaxf(s2 / (float)Cin - mean * mean, 0.0f);
+          const float var = m2 / (float)Cin;
           if (lane < W) {
             st[lane] = mean;
             st[48 + lane] = 1.0f / sqrtf(var + p.ln_eps);
@@ -237,8 +244,10 @@ __global__ __launch_bounds__(BT) void conv_short_kernel(const ConvArgs p, const 
     const int nt = by_tile ? u : u >> 2;
     const int r_lo = by_tile ? 0 : (u & 3), r_hi = by_tile ? 4 : (u & 3) + 1;
     const int col = t0 + 16 * nt + j;
-    float ps1 = 0.0f, ps2 = 0.0f;
-    for (int r = r_lo; r < r_hi; r++) {
+    float ps1 = 0.0f, pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      if (r < r_lo || r >= r_hi) continue;  // wave-uniform
       const int i = 4 * kk + r;  // row of the 16-row tile
       int co;
       bool row_ok;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(BT) void conv_short_kernel(const ConvArgs p, const 
               epi_finish<EPI_STORE>(p, n, row, col, v, e);
               const float val = pres ? v + e.a : v;  // exactly what epi_finish stored
               ps1 += val;
-              ps2 += val * val;
+              pv[r] = val;
             }
           } break;
           case EPI_RELU: if (okp) epi_finish<EPI_RELU>(p, n, row, col, v, EpiIn{}); break;
@@ -289,15 +298,23 @@ __global__ __launch_bounds__(BT) void conv_short_kernel(const ConvArgs p, const 
       }
     }
     if constexpr (!GATE) {
-      if (by_tile) {  // partial LayerNorm sums of this tile's 16 rows per column (ConvArgs::stats_out)
+      if (by_tile) {  // LayerNorm statistics of this tile's 16 rows per column: (Σ y, Σ (y − mean_tile)²) (ConvArgs::stats_out)
+        const float cnt = (float)max(1, min(16, Cout - 16 * mt));
         ps1 += __shfl_xor(ps1, 32, 64);
-        ps2 += __shfl_xor(ps2, 32, 64);
         ps1 += __shfl_xor(ps1, 16, 64);
-        ps2 += __shfl_xor(ps2, 16, 64);
+        const float ms = ps1 / cnt;
+        float q2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float dv = pv[r] - ms;
+          if (16 * mt + 4 * kk + r < Cout) q2 += dv * dv;
+        }
+        q2 += __shfl_xor(q2, 32, 64);
+        q2 += __shfl_xor(q2, 16, 64);
         if (lane < 16 && col < Lout) {
           const int parts = (Cout + 15) >> 4;
           float* sb = p.stats_out + (int64_t)n * parts * p.y_len * 2;
-          *(float2*)(sb + ((int64_t)mt * p.y_len + col) * 2) = make_float2(ps1, ps2);
+          *(float2*)(sb + ((int64_t)mt * p.y_len + col) * 2) = make_float2(ps1, q2);
         }
       }
     }

@@ -1686,6 +1686,11 @@ int check_utt(const piper_hip_voice* v, const piper_hip_utterance* u, int64_t* F
   if (u->t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance: %d ids exceeds the 4096 cap (PiperCLI.swift:394)", u->t);
   if (!u->durations) {  // to be predicted: the frame count is not known yet
     if (!v->cfg.dp_present) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: durations are NULL and the voice has no duration predictor");
+    // `noise` is [inter, F] and F is what the predictor is about to decide: the caller cannot have sized it, and the ABI carries no
+    // size to check it against (in the reference an override tensor brings its shape, TensorValue.swift:4-43)
+    if (u->noise)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance: noise given but durations are NULL — its [inter, F] shape depends on the predicted durations: call "
+                                 "piper_hip_voice_predict_durations first and pass durations + noise, or use noise_mode = DEVICE");
     *F_out = -1;
     return PIPER_HIP_OK;
   }

@@ -88,6 +88,12 @@ int validate_config(const piper_hip_voice_config* c) {
     if (c->dp_present != 1 || c->dp_kernel < 1 || c->dp_kernel > 7 || !(c->dp_kernel & 1) || c->dp_dds_layers < 1 || c->dp_dds_layers > 4 ||
         c->dp_n_flows < 2 || c->dp_n_flows > 8 || c->dp_bins < 2 || c->dp_bins > 32 || !(c->dp_tail_bound > 0.0f) || c->dp_tail_bound > 100.0f)
       PH_FAIL(PIPER_HIP_ERR_SHAPE, "duration predictor geometry unsupported");
+    // what the predictor's kernels cover (dp.hip: dds_layer_eligible, kMaxBins) — checked HERE so that a voice inferred from an
+    // untrusted .onnx is refused at piper_hip_voice_create, not at its first predict
+    if (c->dp_bins > 16) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "duration predictor: %d spline bins (the spline kernel covers at most 16)", c->dp_bins);
+    if (c->hidden < 16 || c->hidden > 256)
+      PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "duration predictor: hidden = %d (the DDSConv layer kernel covers 16 … 256 channels); load the voice with dp_present = 0 "
+                                         "and supply durations", c->hidden);
   }
   return PIPER_HIP_OK;
 }

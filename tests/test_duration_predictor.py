@@ -191,3 +191,34 @@ def test_voice_without_predictor_refuses(backend, voices):
         assert a.size == 42 * cfg.hop
     finally:
         rt.close()
+
+
+def test_predictor_geometry_is_checked_when_the_voice_is_described():
+    """dp_bins up to 32 and hidden up to 4096 used to pass piper_hip_voice_create and fail only at the first predict, inside
+    the plan build. The config check now covers what the predictor's kernels cover (16 bins, 16 … 256 channels) — host-only."""
+    cfg = ph.voice_config("medium")
+    assert ph.blob_floats(cfg) > 0
+    cfg.dp_bins = 20
+    with pytest.raises(ph.UnsupportedOp):
+        ph.blob_floats(cfg)
+    cfg = ph.voice_config("medium")
+    cfg.hidden, cfg.n_heads = 384, 4
+    with pytest.raises(ph.UnsupportedOp):
+        ph.blob_floats(cfg)
+    cfg.dp_present = 0  # the same geometry without the predictor is fine (durations are then supplied)
+    assert ph.blob_floats(cfg) > 0
+
+
+@pytest.mark.gpu
+def test_noise_without_durations_is_refused(rts, voices):
+    """`noise` is [inter, F] and with durations == NULL the caller cannot know F — the buffer would be over-read or
+    mis-strided. Refused with InvalidArgument; the documented routes (predict_durations first, or device noise) work."""
+    rt = rts["medium"]
+    ids = kd.FIXTURE_IDS
+    with pytest.raises(ph.InvalidArgument):
+        rt.prepare(3, ids, None, kd.sym(5, (192, 42), 1.0), 0.667)
+    durs = rt.predict_durations([(ids, None)], noise_mode="device", seed=7)[0][0]
+    F = int(np.sum(durs))
+    rt.prepare(3, ids, durs, kd.sym(5, (192, F), 1.0), 0.667)
+    rt.launch(3)
+    assert rt.collect(3).size == F * 256

@@ -111,6 +111,30 @@ def test_factor8_vs_oracle(rt_medium, voices):
     assert_close(audio, ref_audio, WAVE_TOL, "audio")
 
 
+def test_layernorm_with_common_mode_offset_vs_oracle(backend, voices):
+    """the LayerNorm folded into the convs (statistics in the producer's epilogue, normalise-on-load in the consumer) used a
+    one-pass variance Σy²/C − mean², which loses (mean / sigma)²·6e-8 — harmless on the seeded weights, unpinned for a voice whose residual
+    stream carries a common-mode offset. Here the output projection and the second FFN conv of every encoder layer get a bias of +60 on
+    every channel (mean / sigma of the LayerNorm input ≈ 50 … 100): the encoder output must still match the oracle's two-pass chain
+    (ReduceMean / Sub / Pow / ReduceMean, GraphExecutor.swift:2071-2125) at OP_TOL."""
+    cfg, blob0 = voices["medium"]
+    blob = blob0.copy()
+    for t in ph.blob_layout(cfg):
+        if t["name"].endswith(("conv_o.bias", "conv_2.bias")) and t["name"].startswith("enc_p.encoder"):
+            blob[t["offset"]:t["offset"] + t["count"]] += 60.0
+    rt = ph.HipRuntime(backend, cfg, blob)
+    try:
+        for factor in (1, 8):
+            ids, dur = kd.FIXTURE_IDS * factor, [3] * (14 * factor)
+            noise = kd.sym(SD + 95, (192, 42 * factor), 1.7320508)
+            audio, taps = run_with_taps(rt, ids, dur, noise)
+            ref_audio, ref_taps = orc.synthesize(cfg, blob, ids, dur, noise, 0.667, taps=True)
+            assert_close(taps["enc_out"], ref_taps["enc_out"], OP_TOL, f"enc_out with a +60 common-mode offset (factor {factor})")
+            assert_close(audio, ref_audio, WAVE_TOL, f"audio with a +60 common-mode offset (factor {factor})")
+    finally:
+        rt.close()
+
+
 def test_errors(rt_medium):
     with pytest.raises(ph.ShapeMismatch):
         rt_medium.synthesize([1, 2], [0, 0])  # zero frames
