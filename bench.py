@@ -359,6 +359,7 @@ def main():
                    "factor": args.factor, "phoneme_count": len(ids), "frames": int(sum(dur)), "samples": int(n_samples),
                    "sample_rate": sr, "parallelism": f"utterance-replicas x{world} (one-shot RCCL weight broadcast)"},
         "gpu_ms_mean": round(float(np.mean(gpu_ms)), 4),
+        "tuning_switches": ph.config_string(),  # PIPER_HIP_* A/B switches honoured in this process ("" = the shipped defaults)
         "prepare_ms_cold": round(prepare_cold_ms, 3),
         "prepare_ms_cold_breakdown": dict(cold_breakdown, note="first plan build of the process (it also creates the process's first HIP stream); capture + instantiate run "
                                           "AFTER the eager first launch has been enqueued, overlapping it"),

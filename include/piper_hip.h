@@ -53,6 +53,9 @@ typedef void* piper_hip_stream;                 /* hipStream_t; stands in for MT
 /* Thread-local description of the last failure on this thread ("" if none). */
 const char* piper_hip_last_error(void);
 int piper_hip_abi_version(void);
+/* The tuning / A-B switches (PIPER_HIP_* environment variables) this process has honoured so far, as "NAME=value …"; empty
+ * when none. Switches are honoured only when PIPER_HIP_TUNING=1 is set too: an inherited environment does not change which kernels run. */
+int piper_hip_config_string(char* buf, size_t n);
 /* Number of visible HIP devices (0 when none); never initialises a device. */
 int piper_hip_device_count(void);
 

@@ -15,12 +15,20 @@
 #include "../../include/piper_hip.h"
 
 #define PH_EXPORT extern "C" __attribute__((visibility("default")))
+#include <cstdlib>
 
 namespace ph {
 
 // thread-local error text behind piper_hip_last_error()
 void set_error(const char* fmt, ...);
 const char* get_error();
+
+// Tuning / A-B switches: ≈ 45 PIPER_HIP_* environment variables are read, once each, by the dispatchers. They exist
+// so that every design decision can be re-measured — not so that an inherited environment can silently change which kernel runs
+// (ADVICE r2). Every lookup in this library goes through tuning_getenv (the macro below replaces the C library's getenv in all of
+// csrc/): a PIPER_HIP_* switch is HONOURED only when PIPER_HIP_TUNING=1 is set as well, and every switch that was honoured is
+// recorded and reported by piper_hip_config_string() — bench.py prints it in its JSON line.
+const char* tuning_getenv(const char* name);
 
 #define PH_FAIL(code, ...)        \
   do {                            \
@@ -132,3 +140,7 @@ struct StreamScope {
 int ensure_out(piper_hip_ctx* ctx, float** out, size_t count, int alloc_err_code_note);
 
 }  // namespace ph
+
+// after every include of this header: csrc/ code that says getenv(...) gets the gated, recorded lookup
+#define getenv(name) ::ph::tuning_getenv(name)
+

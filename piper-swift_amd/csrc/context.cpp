@@ -14,6 +14,25 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_err; }
 
+#undef getenv
+static std::mutex g_tune_mu;
+static std::map<std::string, std::string> g_tune_seen;  // switches that were honoured (name → value)
+static int g_tune_ignored = 0;                            // PIPER_HIP_* variables found in the environment but not honoured
+
+const char* tuning_getenv(const char* name) {
+  const char* v = ::getenv(name);
+  if (!v) return nullptr;
+  static const bool enabled = [] { const char* t = ::getenv("PIPER_HIP_TUNING"); return t && t[0] == '1'; }();
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  if (strncmp(name, "PIPER_HIP_", 10) == 0 && !enabled) {
+    g_tune_ignored++;
+    return nullptr;
+  }
+  g_tune_seen[name] = v;
+  return v;
+}
+#define getenv(name) ::ph::tuning_getenv(name)
+
 static size_t bucket_of(size_t bytes) {
   size_t b = 256;
   while (b < bytes) b <<= 1;
@@ -138,6 +157,18 @@ int ensure_out(piper_hip_ctx* ctx, float** out, size_t count, int) {
 
 PH_EXPORT const char* piper_hip_last_error(void) { return ph::get_error(); }
 PH_EXPORT int piper_hip_abi_version(void) { return PIPER_HIP_ABI_VERSION; }
+
+PH_EXPORT int piper_hip_config_string(char* buf, size_t n) {
+  if (!buf || n == 0) PH_FAIL(PIPER_HIP_ERR_ARG, "config_string: null buffer");
+  std::string out;
+  {
+    std::lock_guard<std::mutex> lk(ph::g_tune_mu);
+    for (auto& kv : ph::g_tune_seen) out += (out.empty() ? "" : " ") + kv.first + "=" + kv.second;
+    if (ph::g_tune_ignored) out += (out.empty() ? "" : " ") + std::string("(PIPER_HIP_* variables present but ignored: set PIPER_HIP_TUNING=1 to honour them)");
+  }
+  snprintf(buf, n, "%s", out.c_str());
+  return PIPER_HIP_OK;
+}
 
 PH_EXPORT int piper_hip_device_count(void) {
   int n = 0;

@@ -2033,6 +2033,9 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
       int64_t total = 0;
       for (int b = 0; b < n; b++) {
         if (utts[b].t < 1 || utts[b].t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance %d: bad phoneme count", b);
+        if (!utts[b].durations && utts[b].noise)  // the refusal check_utt makes: here the durations are still NULL, below they are the predicted ones
+          PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: noise given but durations are NULL — its [inter, F] shape depends on the predicted durations: call "
+                                     "piper_hip_voice_predict_durations first and pass durations + noise, or use noise_mode = DEVICE", b);
         total += utts[b].t;
       }
       predicted.resize((size_t)total);

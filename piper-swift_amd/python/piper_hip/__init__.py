@@ -120,6 +120,7 @@ class KernelStat(C.Structure):
 _PROTOS = {
     "piper_hip_last_error": (C.c_char_p, []),
     "piper_hip_abi_version": (C.c_int, []),
+    "piper_hip_config_string": (C.c_int, [C.c_char_p, C.c_size_t]),
     "piper_hip_device_count": (C.c_int, []),
     "piper_hip_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
     "piper_hip_destroy": (None, [c_vp]),
@@ -624,6 +625,13 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     _check(load_library().piper_hip_comm_unique_id(buf))
     return buf.raw
+
+
+def config_string():
+    """The PIPER_HIP_* tuning switches this process has honoured so far (needs PIPER_HIP_TUNING=1), '' when none."""
+    buf = C.create_string_buffer(2048)
+    _check(load_library().piper_hip_config_string(buf, len(buf)))
+    return buf.value.decode()
 
 
 def comm_available():

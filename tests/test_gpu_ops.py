@@ -464,7 +464,7 @@ def test_convtranspose1d_chunk_pipelined_kernel_on_request():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "probe", "convt_pipe_check.py")
-    env = dict(os.environ, PIPER_HIP_PIPE_CT_MIN_GFLOP="0")
+    env = dict(os.environ, PIPER_HIP_PIPE_CT_MIN_GFLOP="0", PIPER_HIP_TUNING="1")  # switches are honoured only with PIPER_HIP_TUNING=1
     env.pop("PIPER_HIP_NO_PIPE", None)
     out = subprocess.run([sys.executable, tool, "0", "4", "5"], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -520,3 +520,28 @@ def test_hifigan_resblock_fused_pairs(case, backend):
     got = b.downloadFloat32(out).reshape(N, Cc, T)
     for n in range(N):
         assert_close(got[n], orc.hifigan_resblock(type_, x[n:n + 1], K, dils, ws, bs)[0], OP_TOL, f"item {n} vs oracle")
+
+
+@pytest.mark.gpu
+def test_tuning_switches_need_an_explicit_opt_in_and_are_reported():
+    """≈ 45 PIPER_HIP_* A/B switches are read by the dispatchers. An inherited environment must not silently change which
+    kernel runs: a switch is honoured only with PIPER_HIP_TUNING=1, and piper_hip_config_string() says which ones were."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, piper_hip as ph, katdata as kd\n"
+            "b = ph.HipBackend(0)\n"
+            "x = b.uploadFloat32(kd.sym(1, (1, 192, 112))); w = b.uploadFloat32(kd.sym(2, (256, 192, 7), 0.05))\n"
+            "b.conv1dF32(x, [1, 192, 112], w, [256, 192, 7], None, 1, 1, 3, 3, 1)\n"
+            "print('CFG[' + ph.config_string() + ']')\n") % (os.path.join(ROOT, "piper-swift_amd", "python"), os.path.join(ROOT, "tests"))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("PIPER_HIP_")}
+    out = subprocess.run([sys.executable, "-c", code], env=dict(base, PIPER_HIP_NO_SHORT="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "PIPER_HIP_NO_SHORT=1" not in out.stdout and "ignored" in out.stdout, out.stdout
+    out = subprocess.run([sys.executable, "-c", code], env=dict(base, PIPER_HIP_NO_SHORT="1", PIPER_HIP_TUNING="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "PIPER_HIP_NO_SHORT=1" in out.stdout, out.stdout
+    out = subprocess.run([sys.executable, "-c", code], env=base, capture_output=True, text=True, timeout=300)
+    assert "CFG[]" in out.stdout, out.stdout

@@ -527,7 +527,7 @@ def test_bf16_fused_pairs_equal_the_two_launch_path(tmp_path):
     env = dict(os.environ)
     env.pop("PIPER_HIP_NO_RB_PAIR", None)
     subprocess.check_call([sys.executable, tool, "run", a], env=env, timeout=300)
-    subprocess.check_call([sys.executable, tool, "run", b], env=dict(env, PIPER_HIP_NO_RB_PAIR="1"), timeout=300)
+    subprocess.check_call([sys.executable, tool, "run", b], env=dict(env, PIPER_HIP_NO_RB_PAIR="1", PIPER_HIP_TUNING="1"), timeout=300)
     out = subprocess.run([sys.executable, tool, "cmp", a, b], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr

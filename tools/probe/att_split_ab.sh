@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 for f in 16 24 32 40 64; do
   for mt in 100000 512 256 128; do

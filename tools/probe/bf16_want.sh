@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 for rep in 1 2; do for w in 1 2 4 8 16 64; do
   for cfg in "--quality high --precision bf16" "--quality medium --precision bf16" "--quality high --precision bf16 --factor 32"; do

@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 for rep in 1 2 3; do for cfg in "--factor 8" "--factor 64" "--factor 8 --batch 8" "--factor 16" "--quality high --factor 2"; do
   echo "new [$cfg]: $(timeout -k 10 120 python tools/profile_steps.py $cfg 2>&1 | head -1)"

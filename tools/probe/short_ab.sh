@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the short-row conv kernel choices: rocprofv3 kernel-trace of the default bench step (graph replay: true in-graph kernel durations)
 # under each environment setting; prints ms/step and the conv kernels' per-instantiation averages.  gpurun -- bash tools/probe/short_ab.sh "A=1" "B=2 C=3" …
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/short_ab
 mkdir -p "$OUT"

@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 for f in 1 2 4; do for m in default NO_WIN NO_FLOW_SEAM NO_MERGED_RB NO_LN_FUSE NO_WIDE_POST; do
   if [ $m = default ]; then v=X; else v=PIPER_HIP_$m; fi

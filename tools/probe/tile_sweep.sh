@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 mkdir -p gpurun_out/tl
 run() { local name=$1; shift; local args=(); while [ "$1" != "--" ]; do args+=("$1"); shift; done; shift

@@ -1,3 +1,4 @@
+export PIPER_HIP_TUNING=1  # the library honours PIPER_HIP_* switches only with this set
 set -e
 mkdir -p gpurun_out/wm
 for m in 1 2 4; do

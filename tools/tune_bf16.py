@@ -31,6 +31,7 @@ for c in cfgs:
     if c == "default":
         os.environ.pop("PIPER_HIP_BF16_CFG", None)
     else:
+        os.environ["PIPER_HIP_TUNING"] = "1"  # switches are honoured only with this set
         os.environ["PIPER_HIP_BF16_CFG"] = c
     rt = ph.HipRuntime(b, cfg, blob)
     rt.set_precision("bf16")
