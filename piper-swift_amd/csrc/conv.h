@@ -95,6 +95,8 @@ int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate);
 bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups);
 // Enqueue one conv on `s`. args.w must already be packed for the MFMA path.
 int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
+// The k = 1 convs of one utterance with a minimal instruction count: conv_lean.hip. Same return convention as try_launch_conv_short.
+int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
 // Short rows (one utterance's encoder / flow convs): conv_short.hip. 1 = enqueued, 0 = not this kernel's case (use launch_conv_mfma's
 // streaming kernel), < 0 = error. Called by launch_conv_mfma.
 int try_launch_conv_short(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);

@@ -524,6 +524,11 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_tile launch failed: %s", hipGetErrorString(e));
     return PIPER_HIP_OK;
   }
+  {  // k = 1, few tiles: the minimal-instruction kernel (conv_lean.hip)
+    const int r = try_launch_conv_lean(ctx, s, a);
+    if (r < 0) return r;
+    if (r == 1) return PIPER_HIP_OK;
+  }
   {  // short rows with few tiles: the LDS-window kernel (conv_short.hip)
     const int r = try_launch_conv_short(ctx, s, a);
     if (r < 0) return r;
