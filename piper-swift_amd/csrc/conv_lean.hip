@@ -99,6 +99,92 @@ __global__ __launch_bounds__(512) void conv_k1_kernel(const LeanArgs a) {
   }
 }
 
+// ---- the WaveNet gated conv (k taps, tanh·sigmoid) of one utterance, same diet ----
+// Weights: the gate-packed 16-row image (8 tanh rows + their 8 sigmoid rows per tile, pack_conv_weights_gate16). 8 waves split the
+// contraction (NQ channel quads each); a wave stages the [4·NQ] × [16 + K − 1] window of ITS channels in its own piece of LDS — the
+// main 16 columns four rows per load, the K − 1 halo columns sixteen rows per load; a position outside [0, true length) is requested
+// at an out-of-range offset, which returns the conv's zero padding without touching memory — and feeds every tap from it.
+struct GateArgs {
+  const float *x, *w, *bias;
+  float* y;
+  const int* len_ptr;
+  int len_mul, Lin, Lout, rows_out, y_len, nsteps, pad, x_batch_bytes;
+  long long x_bs, y_bs;
+};
+
+template <int K, int NQ>
+__global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a) {
+  constexpr int W = 16 + K - 1, PITCH = (W + 3) & ~3, ROWS = 4 * NQ, NS = NQ * K;
+  constexpr int NLB = (ROWS + 15) / 16;  // halo loads: 16 rows × 4 columns each (K − 1 ≤ 4)
+  constexpr int OOB = 0x7fffffff;
+  static_assert(K - 1 <= 4, "halo piece is four columns wide");
+  __shared__ float xs_all[8 * ROWS * PITCH];
+  __shared__ float red[8 * 4 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
+  int Lv = a.Lin;
+  if (a.len_ptr) {
+    Lv = min(a.len_ptr[n] * a.len_mul, a.Lin);
+    if (t0 >= Lv) return;  // a chunk past the item's true length produces nothing anyone reads
+  }
+  const int j = lane & 15, kk = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
+  const float* wa = a.w + (((long long)mt * a.nsteps + wave * NS) << 6) + lane;
+  float av[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
+  // window: main piece (column j of rows 4i + kk), halo piece (column 16 + (lane & 3) of rows 16i + (lane >> 2))
+  const int posA = t0 - a.pad + j;
+  const int voffA = (posA >= 0 && posA < Lv) ? (kk * a.Lin + posA) * 4 : OOB;
+  const int rB = lane >> 2, cB = 16 + (lane & 3);
+  const int posB = t0 - a.pad + cB;
+  const int voffB = ((lane & 3) < K - 1 && posB >= 0 && posB < Lv) ? (rB * a.Lin + posB) * 4 : OOB;
+  const int sbase = wave * ROWS * a.Lin * 4;
+  float xa[NQ], xb[NLB];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
+#pragma unroll
+  for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < ROWS) ? voffB : OOB, sbase + i * 64 * a.Lin);
+  float* xs = xs_all + wave * (ROWS * PITCH);
+#pragma unroll
+  for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];
+#pragma unroll
+  for (int i = 0; i < NLB; i++)
+    if ((lane & 3) < K - 1 && rB + 16 * i < ROWS) xs[(rB + 16 * i) * PITCH + cB] = xb[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* xw = xs + kk * PITCH + j;
+#pragma unroll
+  for (int qi = 0; qi < NQ; qi++)
+#pragma unroll
+    for (int k = 0; k < K; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[qi * K + k], xw[4 * qi * PITCH + k], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave >= 4) return;
+  // wave w finishes register w: tile rows i = 4·kk + w — lanes 0–31 hold tanh rows (i < 8), lanes 32–63 their sigmoid partners
+  const int i = 4 * kk + wave;
+  const int h = 8 * mt + (i & 7);
+  float v = a.bias ? a.bias[(i < 8 ? 0 : a.rows_out) + min(h, a.rows_out - 1)] : 0.0f;  // bias first (CPUBackend.swift:46-63)
+  float part[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < 8; s++) v += part[s];
+  const float sg = __shfl_xor(v, 32, 64);
+  const int col = t0 + j;
+  if (lane < 32 && h < a.rows_out && col < a.Lout) {
+    const float ta = tanhf(v);
+    float g;  // the stable sigmoid form of elementwise.metal:253-268
+    if (sg >= 0.0f) { const float z = expf(-sg); g = 1.0f / (1.0f + z); }
+    else { const float z = expf(sg); g = z / (1.0f + z); }
+    a.y[(long long)n * a.y_bs + (long long)h * a.y_len + col] = ta * g;
+  }
+}
+
 template <int NQ>
 bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
   switch (mode) {
@@ -116,7 +202,24 @@ bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
 int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
   static const bool off = getenv("PIPER_HIP_NO_LEAN") != nullptr;
   if (off) return 0;
-  if (c.K != 1 || c.gate || c.prologue != PRO_NONE || c.stats_out || !c.w16) return 0;
+  if (c.gate) {  // the flow's gated conv: k 5 (3), 192 (96) channels, identity channel maps
+    if (!c.w16g || c.prologue != PRO_NONE || c.epilogue != EPI_STORE || c.res || c.stats_out || c.dil != 1 || c.Lin != c.Lout || (c.Cout % 16)) return 0;
+    if (c.in_ch_sign != 1 || c.in_ch_base != 0 || c.out_ch_sign != 1 || c.out_ch_base != 0 || c.N > 65535) return 0;
+    if ((c.K != 5 && c.K != 3) || c.Cin != 192 || c.padL != (c.K - 1) / 2) return 0;
+    const int mt_g = c.Cout / 16, nch = (int)ceil_div(c.Lout, 16);
+    if ((int64_t)mt_g * nch * c.N > 8 * (int64_t)ctx->num_cus || nch > 65535 || c.x_batch_stride * 4 >= 0x7fffffffLL) return 0;
+    GateArgs g;
+    g.x = c.x; g.w = c.w16g; g.bias = c.bias; g.y = c.y; g.len_ptr = c.len_ptr; g.len_mul = c.len_mul;
+    g.Lin = c.Lin; g.Lout = c.Lout; g.rows_out = c.Cout / 2; g.y_len = c.y_len; g.nsteps = (c.Cin / 4) * c.K; g.pad = c.padL;
+    g.x_batch_bytes = (int)(c.x_batch_stride * 4); g.x_bs = c.x_batch_stride; g.y_bs = c.y_batch_stride;
+    const dim3 grid((unsigned)mt_g, (unsigned)nch, (unsigned)c.N);
+    if (c.K == 5) hipLaunchKernelGGL((conv_gate_kernel<5, 6>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((conv_gate_kernel<3, 6>), grid, dim3(512), 0, s, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_gate launch failed: %s", hipGetErrorString(e));
+    return 1;
+  }
+  if (c.K != 1 || c.prologue != PRO_NONE || c.stats_out || !c.w16) return 0;
   if (c.epilogue != EPI_STORE && c.epilogue != EPI_RSUB && c.epilogue != EPI_WN_RES_SKIP && c.epilogue != EPI_WN_SKIP_LAST) return 0;
   if ((c.epilogue == EPI_RSUB || c.epilogue == EPI_WN_RES_SKIP) && !c.res) return 0;
   if (c.Cin % 32 || c.padL != 0 || c.Lin != c.Lout || c.N > 65535 || c.Lout < 1) return 0;
