@@ -15,7 +15,7 @@ for f in bench_factor64 bench_high_bf16 bench_high_f32 bench_medium_bf16; do cp 
 cp $R/bench_full.json profiles/${TAG}_bench_full_with_cpu_baseline.json
 for f in steps_factor64 steps_factor8 steps_factor8_batch8 steps_high_bf16 steps_high_f32 steps_medium_bf16; do cp $R/$f.txt profiles/${TAG}_$f.txt; done
 mkdir -p profiles/${TAG}_raw
-for c in f32 f64 high_bf16 high_f32; do cp $R/${c}_stats/runc/*_kernel_stats.csv profiles/${TAG}_raw/${c}_kernel_stats.csv; done
+for c in f32 f64 high_bf16 high_f32; do cp "$(ls -t $R/${c}_stats/runc/*_kernel_stats.csv | head -1)" profiles/${TAG}_raw/${c}_kernel_stats.csv; done
 python - <<PY
 import json
 for f in ["bench_full_with_cpu_baseline","bench_factor64","bench_high_f32","bench_high_bf16","bench_medium_bf16"]:
