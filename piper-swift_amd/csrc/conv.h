@@ -78,6 +78,7 @@ struct ConvArgs {
   const float* ln_beta = nullptr;
   float* ln_out = nullptr;
   float ln_eps = 1e-5f;
+  int ln_self = 0;  // PRO_LN without ln_stats: the consumer computes the statistics of its own operand (conv_lean.hip; conv_lean_ln_self_ok says when)
 };
 
 // number of floats of the packed fragment image for a [Cout, Cin, K] conv
@@ -97,6 +98,7 @@ bool conv_mfma_eligible(int Cout, int Cin, int K, int stride, int groups);
 int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
 // The k = 1 convs of one utterance with a minimal instruction count: conv_lean.hip. Same return convention as try_launch_conv_short.
 int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);
+bool conv_lean_ln_self_ok(piper_hip_ctx* ctx, int Cin, int Cout, int K, int padL, int L, int N);
 // Short rows (one utterance's encoder / flow convs): conv_short.hip. 1 = enqueued, 0 = not this kernel's case (use launch_conv_mfma's
 // streaming kernel), < 0 = error. Called by launch_conv_mfma.
 int try_launch_conv_short(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a);

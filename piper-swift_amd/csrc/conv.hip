@@ -513,7 +513,7 @@ int launch_conv_mfma(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_in) {
   if (a.N > 65535) PH_FAIL(PIPER_HIP_ERR_SHAPE, "conv: batch %d too large", a.N);
   if (!k_supported(a.K)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: no streaming kernel for %d taps", a.K);
   if (a.gate && (a.Cout % 64)) PH_FAIL(PIPER_HIP_ERR_SHAPE, "gated conv needs Cout %% 64 == 0 (got %d)", a.Cout);
-  if (a.prologue == PRO_LN && (!a.ln_stats || !a.ln_gamma || !a.ln_beta || a.in_ch_sign != 1 || a.in_ch_base != 0 || a.dil < 1 || (a.K != 1 && a.K != 3)))
+  if (a.prologue == PRO_LN && ((!a.ln_stats && !a.ln_self) || !a.ln_gamma || !a.ln_beta || a.in_ch_sign != 1 || a.in_ch_base != 0 || a.dil < 1 || (a.K != 1 && a.K != 3)))
     PH_FAIL(PIPER_HIP_ERR_ARG, "conv_mfma: PRO_LN needs statistics, gamma, beta, the identity channel map and K in {1, 3}");
   if (a.prologue == PRO_LN && a.Cin > 256) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_mfma: PRO_LN covers at most 256 normalised channels");
   if (a.stats_out && (a.epilogue != EPI_STORE || a.gate || a.out_ch_sign != 1 || a.out_ch_base != 0))

@@ -185,6 +185,229 @@ __global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a) {
   }
 }
 
+// ---- the same two shapes behind a LayerNorm that the CONSUMER computes itself (ConvArgs::ln_self) ----
+// A block holds every channel of its columns (8 waves × 4·NQ rows), so the channel LayerNorm of the graph (ReduceMean / Sub / Pow /
+// ReduceMean / Add ε / Sqrt / Div / Mul γ / Add β, GraphExecutor.swift:2071-2125) needs nothing from the producer: each wave reduces its
+// rows per column (lane shuffles), the waves exchange (Σ, centred Σ²) through LDS and combine them with Chan's formula (two-pass
+// accuracy), and the operand is normalised in registers before it meets the matrix pipe. Until round 3 the producer's epilogue wrote
+// per-slot statistics and the consumer re-read them (12 float2 loads per column and wave, ≈ 650 vector instructions per wave in the
+// k = 3 case). The blocks of row tile 0 also write the normalised tensor (the residual operand of the next Add, the `enc_out` tap).
+struct LnArgs {
+  const float *gamma, *beta;
+  float* ln_out;
+  float eps;
+};
+
+template <int NQ>
+__global__ __launch_bounds__(512) void conv_k1_ln_kernel(const LeanArgs a, const LnArgs ln) {
+  constexpr int RW = 4 * NQ, C = 8 * RW;  // rows per wave, channels
+  __shared__ float red[8 * 4 * 64];
+  __shared__ float2 st[8 * 16];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
+  if (a.len_ptr) {
+    if (t0 >= a.len_ptr[n] * a.len_mul) return;
+  }
+  const int j = lane & 15, kk = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
+  const float* wa = a.w + (((long long)mt * a.nsteps + wave * NQ) << 6) + lane;
+  const int voff = kk * a.x_row_bytes + min(t0 + j, a.Lin - 1) * 4;
+  const int soff0 = wave * NQ * a.q_stride;
+  float av[NQ], bv[NQ], gv[NQ], bev[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) av[i] = wa[i * 64];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    gv[i] = ln.gamma[4 * (wave * NQ + i) + kk];
+    bev[i] = ln.beta[4 * (wave * NQ + i) + kk];
+  }
+  // the wave's rows of column j: Σ and the Σ² centred on the wave's own mean
+  float s1 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) s1 += bv[i];
+  s1 += __shfl_xor(s1, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  const float mw = s1 * (1.0f / RW);
+  float q2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) q2 += (bv[i] - mw) * (bv[i] - mw);
+  q2 += __shfl_xor(q2, 16, 64);
+  q2 += __shfl_xor(q2, 32, 64);
+  if (lane < 16) st[wave * 16 + lane] = make_float2(s1, q2);
+  __syncthreads();
+  float2 pr[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) pr[w] = st[w * 16 + j];
+  float tot = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 8; w++) tot += pr[w].x;
+  const float mean = tot / (float)C;
+  float m2 = 0.0f;
+#pragma unroll
+  for (int w = 0; w < 8; w++) {
+    const float dm = pr[w].x * (1.0f / RW) - mean;
+    m2 += pr[w].y + (float)RW * (dm * dm);
+  }
+  const float rstd = 1.0f / sqrtf(m2 / (float)C + ln.eps);
+#pragma unroll
+  for (int i = 0; i < NQ; i++) bv[i] = ((bv[i] - mean) * rstd) * gv[i] + bev[i];
+  if (mt == 0 && ln.ln_out && t0 + j < a.Lin) {  // block-uniform but for the column test
+    float* lo = ln.ln_out + (long long)n * a.x_bs + (long long)(4 * wave * NQ + kk) * a.Lin + t0 + j;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) lo[(long long)4 * i * a.Lin] = bv[i];
+  }
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < NQ; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave >= 4) return;
+  const int row = 16 * mt + 4 * kk + wave, col = t0 + j;
+  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float part[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < 8; s++) v += part[s];
+  if (row < a.Cout && col < a.Lout) a.y[(long long)n * a.y_bs + (long long)row * a.y_len + col] = v;
+}
+
+// k = 3 ('same' padding 1 / 1) behind the self-computed LayerNorm, ReLU or plain store out: the encoder FFN's first conv.
+template <int NQ, int MODE>
+__global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const LnArgs ln) {
+  constexpr int K = 3, W = 18, PITCH = 20, RW = 4 * NQ, C = 8 * RW, NS = NQ * K;
+  constexpr int NLB = (RW + 15) / 16;
+  constexpr int OOB = 0x7fffffff;
+  __shared__ float xs_all[8 * RW * PITCH];
+  __shared__ float red[8 * 4 * 64];
+  __shared__ float2 st[8 * W];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
+  int Lv = a.Lin;
+  if (a.len_ptr) {
+    Lv = min(a.len_ptr[n] * a.len_mul, a.Lin);
+    if (t0 >= Lv) return;
+  }
+  const int j = lane & 15, kk = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
+  const float* wa = a.w + (((long long)mt * a.nsteps + wave * NS) << 6) + lane;
+  float av[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
+  // window columns 0 … 15 ↔ positions t0 − 1 … t0 + 14 (main piece), columns 16, 17 ↔ t0 + 15, t0 + 16 (halo piece)
+  const int posA = t0 - 1 + j;
+  const bool okA = posA >= 0 && posA < Lv;
+  const int voffA = okA ? (kk * a.Lin + posA) * 4 : OOB;
+  const int rB = lane >> 2, cB = lane & 3;
+  const int posB = t0 + 15 + cB;
+  const bool okB = cB < 2 && posB < Lv;
+  const int voffB = okB ? (rB * a.Lin + posB) * 4 : OOB;
+  const int sbase = wave * RW * a.Lin * 4;
+  const int ch0 = wave * RW;  // first channel of this wave
+  float xa[NQ], xb[NLB], ga[NQ], ba[NQ], gb[NLB], bb[NLB];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
+#pragma unroll
+  for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < RW) ? voffB : OOB, sbase + i * 64 * a.Lin);
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    ga[i] = ln.gamma[ch0 + 4 * i + kk];
+    ba[i] = ln.beta[ch0 + 4 * i + kk];
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; i++) {
+    const int ch = ch0 + min(rB + 16 * i, RW - 1);
+    gb[i] = ln.gamma[ch];
+    bb[i] = ln.beta[ch];
+  }
+  // per window column: Σ and centred Σ² over this wave's RW rows — main columns by lanes (kk, j), halo columns by lanes (rB, cB)
+  float s1 = 0.0f, h1 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) s1 += xa[i];
+  s1 += __shfl_xor(s1, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+#pragma unroll
+  for (int i = 0; i < NLB; i++) h1 += (rB + 16 * i < RW) ? xb[i] : 0.0f;
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) h1 += __shfl_xor(h1, m, 64);
+  const float mwA = s1 * (1.0f / RW), mwB = h1 * (1.0f / RW);
+  float q2 = 0.0f, hq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) q2 += (xa[i] - mwA) * (xa[i] - mwA);
+  q2 += __shfl_xor(q2, 16, 64);
+  q2 += __shfl_xor(q2, 32, 64);
+#pragma unroll
+  for (int i = 0; i < NLB; i++) hq += (rB + 16 * i < RW) ? (xb[i] - mwB) * (xb[i] - mwB) : 0.0f;
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) hq += __shfl_xor(hq, m, 64);
+  if (lane < 16) st[wave * W + lane] = make_float2(s1, q2);
+  if (lane < 2) st[wave * W + 16 + lane] = make_float2(h1, hq);  // lanes 0, 1: rB = 0, cB = lane
+  __syncthreads();
+  auto column_stats = [&](const int colw, float& mean, float& rstd) {
+    float2 pr[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) pr[w] = st[w * W + colw];
+    float tot = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) tot += pr[w].x;
+    mean = tot / (float)C;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const float dm = pr[w].x * (1.0f / RW) - mean;
+      m2 += pr[w].y + (float)RW * (dm * dm);
+    }
+    rstd = 1.0f / sqrtf(m2 / (float)C + ln.eps);
+  };
+  float meanA, rstdA, meanB, rstdB;
+  column_stats(j, meanA, rstdA);
+  column_stats(16 + min(cB, 1), meanB, rstdB);
+  float* xs = xs_all + wave * (RW * PITCH);
+  const bool wr = mt == 0 && ln.ln_out != nullptr;
+  float* lo = ln.ln_out + (long long)n * a.x_bs;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    const float v = okA ? ((xa[i] - meanA) * rstdA) * ga[i] + ba[i] : 0.0f;  // the conv zero-pads the NORMALISED tensor
+    xs[(4 * i + kk) * PITCH + j] = v;
+    if (wr && okA && j >= 1) lo[(long long)(ch0 + 4 * i + kk) * a.Lin + posA] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; i++) {
+    const float v = okB ? ((xb[i] - meanB) * rstdB) * gb[i] + bb[i] : 0.0f;
+    if (cB < 2 && rB + 16 * i < RW) {
+      xs[(rB + 16 * i) * PITCH + 16 + cB] = v;
+      if (wr && okB && cB == 0) lo[(long long)(ch0 + rB + 16 * i) * a.Lin + posB] = v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* xw = xs + kk * PITCH + j;
+#pragma unroll
+  for (int qi = 0; qi < NQ; qi++)
+#pragma unroll
+    for (int k = 0; k < K; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[qi * K + k], xw[4 * qi * PITCH + k], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave >= 4) return;
+  const int row = 16 * mt + 4 * kk + wave, col = t0 + j;
+  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float part[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < 8; s++) v += part[s];
+  if constexpr (MODE == EPI_RELU) v = v > 0.0f ? v : 0.0f;
+  if (row < a.Cout && col < a.Lout) a.y[(long long)n * a.y_bs + (long long)row * a.y_len + col] = v;
+}
+
 template <int NQ>
 bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
   switch (mode) {
@@ -197,6 +420,16 @@ bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
 }
 
 }  // namespace
+
+// Can a conv behind a LayerNorm compute the statistics itself (ConvArgs::ln_self)? The block must hold every channel (192 = 8 waves × 24
+// rows) and the launch must be one this file takes (few tiles). The schedule builder asks BEFORE it decides how the producer hands the
+// LayerNorm over (voice.hip), so producer and consumer always agree.
+bool conv_lean_ln_self_ok(piper_hip_ctx* ctx, int Cin, int Cout, int K, int padL, int L, int N) {
+  static const bool off = getenv("PIPER_HIP_NO_LEAN") != nullptr || getenv("PIPER_HIP_NO_LN_SELF") != nullptr;
+  if (off || Cin != 192 || (K != 1 && K != 3) || padL != (K - 1) / 2 || L < 1 || N < 1 || N > 65535) return false;
+  const int64_t tiles = ceil_div(Cout, 16) * ceil_div(L, 16) * (int64_t)N;
+  return tiles <= 8 * (int64_t)ctx->num_cus && ceil_div(L, 16) <= 65535 && (int64_t)Cin * L * 4 < 0x7fffffffLL;
+}
 
 // 1 = enqueued, 0 = not this kernel's case, < 0 = error. Called by launch_conv_mfma ahead of the general short-row kernels.
 int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
@@ -217,6 +450,29 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
     else hipLaunchKernelGGL((conv_gate_kernel<3, 6>), grid, dim3(512), 0, s, g);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_gate launch failed: %s", hipGetErrorString(e));
+    return 1;
+  }
+  if (c.prologue == PRO_LN && c.ln_self) {  // LayerNorm computed by the consumer itself: qkv / proj (k 1) and the FFN's first conv (k 3)
+    if (!conv_lean_ln_self_ok(ctx, c.Cin, c.Cout, c.K, c.padL, c.Lout, c.N)) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv: ln_self on a shape conv_lean does not cover");
+    if (!c.w16 || c.stats_out || c.res || c.dil != 1 || c.Lin != c.Lout || c.in_ch_sign != 1 || c.in_ch_base != 0 || c.out_ch_sign != 1 || c.out_ch_base != 0 ||
+        !c.ln_gamma || !c.ln_beta || (c.epilogue != EPI_STORE && c.epilogue != EPI_RELU) || (c.K == 1 && c.epilogue != EPI_STORE))
+      PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv: ln_self needs the plain channel maps and a store / ReLU epilogue");
+    LeanArgs a;
+    a.x = c.x; a.w = c.w16; a.bias = c.bias; a.res = nullptr; a.skip = nullptr; a.y = c.y; a.y2 = nullptr;
+    a.len_ptr = c.len_ptr; a.len_mul = c.len_mul;
+    a.Lin = c.Lin; a.Lout = c.Lout; a.Cout = c.Cout; a.y_len = c.y_len; a.wn_c = 0;
+    a.nsteps = (c.Cin / 4) * c.K;
+    a.x_row_bytes = c.Lin * 4; a.kk_sign = 1; a.x_base_bytes = 0; a.q_stride = 16 * c.Lin;
+    a.out_ch_base = 0; a.out_ch_sign = 1;
+    a.x_batch_bytes = (int)(c.x_batch_stride * 4);
+    a.x_bs = c.x_batch_stride; a.y_bs = c.y_batch_stride; a.y2_bs = 0;
+    LnArgs ln{c.ln_gamma, c.ln_beta, c.ln_out, c.ln_eps};
+    const dim3 grid((unsigned)ceil_div(c.Cout, 16), (unsigned)ceil_div(c.Lout, 16), (unsigned)c.N);
+    if (c.K == 1) hipLaunchKernelGGL((conv_k1_ln_kernel<6>), grid, dim3(512), 0, s, a, ln);
+    else if (c.epilogue == EPI_RELU) hipLaunchKernelGGL((conv_k3_ln_kernel<6, EPI_RELU>), grid, dim3(512), 0, s, a, ln);
+    else hipLaunchKernelGGL((conv_k3_ln_kernel<6, EPI_STORE>), grid, dim3(512), 0, s, a, ln);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_lean (LayerNorm) launch failed: %s", hipGetErrorString(e));
     return 1;
   }
   if (c.K != 1 || c.prologue != PRO_NONE || c.stats_out || !c.w16) return 0;

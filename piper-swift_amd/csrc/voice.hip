@@ -1166,9 +1166,15 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
   float* st1 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   float* st2 = ln_ok ? ar.f32(B * (size_t)ceil_div(H, 16) * T * 2) : nullptr;
   if (ar.rc) return ar.rc;
+  // Round 3: where conv_lean.hip takes all three consumers (qkv, ffn1, proj of one utterance: a block holds every channel of its
+  // columns), the CONSUMER computes the LayerNorm statistics of its own operand (ConvArgs::ln_self) and the producers are plain
+  // residual adds — no statistics tensor crosses the kernel boundary.
+  const bool ln_self = ln_ok && mode != 2 && conv_lean_ln_self_ok(ctx, H, 3 * H, 1, 0, T, NB) && conv_lean_ln_self_ok(ctx, H, c.ffn, kf, (kf - 1) / 2, T, NB) &&
+                       conv_lean_ln_self_ok(ctx, H, 2 * I, 1, 0, T, NB);
   auto with_ln = [&](ConvArgs a, const float* stats, const float* g, const float* be, float* normalised) {
     a.prologue = PRO_LN;
-    a.ln_stats = stats; a.ln_gamma = g; a.ln_beta = be; a.ln_out = normalised; a.ln_eps = 1e-5f;
+    a.ln_stats = ln_self ? nullptr : stats; a.ln_self = ln_self ? 1 : 0;
+    a.ln_gamma = g; a.ln_beta = be; a.ln_out = normalised; a.ln_eps = 1e-5f;
     return a;
   };
   for (int l = 0; l < c.n_layers; l++) {
@@ -1227,8 +1233,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
     }
     if (ln_ok) {  // y = x + conv_o(att) with its LayerNorm statistics; the normalisation itself happens in ffn1's prologue
       ConvArgs a = plain(att, y, H, H, T, lensT);
-      a.res = x; a.stats_out = st1;
-      add_conv(v, s, p + "o_add_stats", L.o, a, T);
+      a.res = x; a.stats_out = ln_self ? nullptr : st1;
+      add_conv(v, s, p + (ln_self ? "o_add" : "o_add_stats"), L.o, a, T);
       ln1_pending = true;
     } else {
     add_conv(v, s, p + "o", L.o, plain(att, y, H, H, T, lensT), T);
@@ -1243,8 +1249,8 @@ int build_schedule(piper_hip_voice* v, Slot& s, int T, int F, int NB, int mode =
       add_conv(v, s, p + (ln1_pending ? "ln1_ffn1_relu" : "ffn1_relu"), L.f1, a, T);
       ConvArgs b = plain(ff, y, c.ffn, H, T, lensT);
       b.padL = (kf - 1) / 2;
-      if (ln_ok) { b.res = x1; b.stats_out = st2; }
-      add_conv(v, s, p + (ln_ok ? "ffn2_add_stats" : "ffn2"), L.f2, b, T);
+      if (ln_ok) { b.res = x1; b.stats_out = ln_self ? nullptr : st2; }
+      add_conv(v, s, p + (ln_self ? "ffn2_add" : ln_ok ? "ffn2_add_stats" : "ffn2"), L.f2, b, T);
     }
     if (!ln_ok) add_ln(p + "add_ln2", x1, y, L.g2, L.b2, x);
   }
