@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* x3 = nullptr;
   const float* w = nullptr;   // MFMA path: packed 32-wide fragments (pack_conv_weights); direct path: raw ONNX layout
   const float* w16 = nullptr; // optional packed 16-wide fragments (short-utterance geometry)
+  const float* w8 = nullptr;   // optional 8-row fragment image (pack_conv_weights_rows8): many input channels, few output rows (conv_lean.hip)
   const float* w16g = nullptr; // gated convs: 16-wide fragments with 8 tanh rows + their 8 sigmoid rows per tile (pack_conv_weights_gate16; conv_short.hip)
   const float* bias = nullptr;
   const float* res = nullptr;   // residual / minuend, same addressing as y
@@ -89,6 +90,9 @@ int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, f
 int pack_convt_weights(hipStream_t s, const float* w, int Cin, int Cout, int K, int stride, float* packed, int tm = 32);
 // gated conv (Cout = 2·H rows, tanh half then sigmoid half): 16-row tiles of rows {8m … 8m+7} ∪ {H + 8m … H + 8m+7}; same size as the tm = 16 image
 int pack_conv_weights_gate16(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
+// 8-row tiles: [ceil(Cout/8)][Cin/4 · K steps][32 floats = 4 channels × 8 rows]; Cin % 4 == 0
+size_t packed_conv_rows8_floats(int Cout, int Cin, int K);
+int pack_conv_weights_rows8(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed);
 // tile geometry launch_conv_mfma will pick for this problem when 16-wide fragments are available (32 or 16)
 int conv_pick_tile(piper_hip_ctx* ctx, int Cout, int Lout, int N, int gate);
 

@@ -55,6 +55,19 @@ __global__ __launch_bounds__(kBlock) void pack_conv_kernel(const float* __restri
   }
 }
 
+// 8-row fragments: element (k = channel of the quad, i = row of the tile) at [tile][step = (quad, tap)][k·8 + i]
+__global__ __launch_bounds__(kBlock) void pack_conv_rows8_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int K, int mtiles, int nsteps) {
+  const int64_t total = (int64_t)mtiles * nsteps * 32;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int l = (int)(i & 31);
+    const int64_t ms = i >> 5;
+    const int step = (int)(ms % nsteps), mt = (int)(ms / nsteps);
+    const int cp = step / K, tap = step - cp * K;
+    const int co = mt * 8 + (l & 7), ci = 4 * cp + (l >> 3);
+    out[i] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * K + tap] : 0.0f;
+  }
+}
+
 // ConvTranspose [Cin, Cout, K], stride s → GEMM rows (co, phase), taps j: weight W[ci][co][phase + s·j]
 __global__ __launch_bounds__(kBlock) void pack_convt_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
                                                             int K, int s, int J, int mtiles, int nsteps, int tm) {
@@ -469,6 +482,16 @@ int pack_conv_weights(hipStream_t s, const float* w, int Cout, int Cin, int K, f
   if (total == 0) return PIPER_HIP_OK;
   const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
   hipLaunchKernelGGL(pack_conv_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps, tm, 0);
+  return PIPER_HIP_OK;
+}
+
+size_t packed_conv_rows8_floats(int Cout, int Cin, int K) { return (size_t)ceil_div(Cout, 8) * (size_t)((Cin + 3) / 4) * K * 32; }
+int pack_conv_weights_rows8(hipStream_t s, const float* w, int Cout, int Cin, int K, float* packed) {
+  const int mtiles = (int)ceil_div(Cout, 8), nsteps = ((Cin + 3) / 4) * K;
+  const int64_t total = (int64_t)mtiles * nsteps * 32;
+  if (total == 0) return PIPER_HIP_OK;
+  const int grid = (int)std::min<int64_t>(ceil_div(total, kBlock), 4096);
+  hipLaunchKernelGGL(pack_conv_rows8_kernel, dim3(grid), dim3(kBlock), 0, s, w, packed, Cout, Cin, K, mtiles, nsteps);
   return PIPER_HIP_OK;
 }
 

@@ -408,6 +408,78 @@ __global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const
   if (row < a.Cout && col < a.Lout) a.y[(long long)n * a.y_bs + (long long)row * a.y_len + col] = v;
 }
 
+// ---- k = 3 with MANY input channels and few output rows (the FFN's second conv: 768 → 192 on ≤ 900 columns) ----
+// 16-row tiles give 12 × 7 = 84 blocks at factor 8, each pulling a 147 KB weight slab: a third of the chip busy on the launch's
+// largest byte stream. Here a tile has EIGHT rows (fragment image `w8`: 128 bytes per contraction step; rows 8 … 15 of the MFMA tile
+// are zero and cost nothing to fetch — their lanes ask at an out-of-range offset): twice the blocks, half the slab each.
+// 8 waves × NQ channel quads; the wave's [4·NQ] × 18 window goes through its own piece of LDS as in conv_gate_kernel.
+template <int NQ>
+__global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const int w_bytes) {
+  constexpr int K = 3, PITCH = 20, RW = 4 * NQ, NS = NQ * K;
+  constexpr int NLB = (RW + 15) / 16;
+  constexpr int OOB = 0x7fffffff;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* red = sm;                      // [8][4][64]
+  float* xs = sm + 8 * 4 * 64 + (threadIdx.x >> 6) * (RW * PITCH);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
+  int Lv = a.Lin;
+  if (a.len_ptr) {
+    Lv = min(a.len_ptr[n] * a.len_mul, a.Lin);
+    if (t0 >= Lv) return;
+  }
+  const int j = lane & 15, kk = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+  const int voffW = j < 8 ? (kk * 8 + j) * 4 : OOB;  // A[i = j][k = kk] of an 8-row fragment
+  const int sW = (mt * a.nsteps + wave * NS) * 128;
+  float av[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) av[s] = bload(rw, voffW, sW + s * 128);
+  const int posA = t0 - 1 + j;
+  const int voffA = (posA >= 0 && posA < Lv) ? (kk * a.Lin + posA) * 4 : OOB;
+  const int rB = lane >> 2, cB = lane & 3;
+  const int posB = t0 + 15 + cB;
+  const int voffB = (cB < 2 && posB < Lv) ? (rB * a.Lin + posB) * 4 : OOB;
+  const int sbase = wave * RW * a.Lin * 4;
+  float xa[NQ], xb[NLB];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
+#pragma unroll
+  for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < RW) ? voffB : OOB, sbase + i * 64 * a.Lin);
+#pragma unroll
+  for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];
+#pragma unroll
+  for (int i = 0; i < NLB; i++)
+    if (cB < 2 && rB + 16 * i < RW) xs[(rB + 16 * i) * PITCH + 16 + cB] = xb[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* xw = xs + kk * PITCH + j;
+#pragma unroll
+  for (int qi = 0; qi < NQ; qi++)
+#pragma unroll
+    for (int k = 0; k < K; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[qi * K + k], xw[4 * qi * PITCH + k], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  if (wave >= 4) return;
+  // wave w finishes register w: tile rows 4·kk + w — only kk < 2 are real rows (lanes 0–31)
+  const int row = 8 * mt + 4 * kk + wave, col = t0 + j;
+  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float part[8];
+#pragma unroll
+  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+  for (int s = 0; s < 8; s++) v += part[s];
+  if (lane < 32 && row < a.Cout && col < a.Lout) {
+    const long long idx = (long long)n * a.y_bs + (long long)row * a.y_len + col;
+    a.y[idx] = a.res ? v + a.res[idx] : v;
+  }
+}
+
 template <int NQ>
 bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
   switch (mode) {
@@ -474,6 +546,28 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_lean (LayerNorm) launch failed: %s", hipGetErrorString(e));
     return 1;
+  }
+  if (c.K == 3 && c.w8 && c.Cin == 768 && c.prologue == PRO_NONE && c.epilogue == EPI_STORE && !c.stats_out && !c.gate && c.dil == 1 && c.padL == 1 &&
+      c.Lin == c.Lout && c.in_ch_sign == 1 && c.in_ch_base == 0 && c.out_ch_sign == 1 && c.out_ch_base == 0 && c.N <= 65535) {
+    const int mt8 = (int)ceil_div(c.Cout, 8), nch = (int)ceil_div(c.Lout, 16);
+    if ((int64_t)mt8 * nch * c.N <= 8 * (int64_t)ctx->num_cus && nch <= 65535 && c.x_batch_stride * 4 < 0x7fffffffLL) {
+      LeanArgs a;
+      a.x = c.x; a.w = c.w8; a.bias = c.bias; a.res = c.res; a.skip = nullptr; a.y = c.y; a.y2 = nullptr;
+      a.len_ptr = c.len_ptr; a.len_mul = c.len_mul;
+      a.Lin = c.Lin; a.Lout = c.Lout; a.Cout = c.Cout; a.y_len = c.y_len; a.wn_c = 0; a.nsteps = (c.Cin / 4) * c.K;
+      a.x_row_bytes = c.Lin * 4; a.kk_sign = 1; a.x_base_bytes = 0; a.q_stride = 16 * c.Lin; a.out_ch_base = 0; a.out_ch_sign = 1;
+      a.x_batch_bytes = (int)(c.x_batch_stride * 4); a.x_bs = c.x_batch_stride; a.y_bs = c.y_batch_stride; a.y2_bs = 0;
+      const int w_bytes = mt8 * a.nsteps * 128;
+      constexpr int NQ = 24;
+      const size_t lds = (size_t)(8 * 4 * 64 + 8 * (4 * NQ) * 20) * sizeof(float);
+      static bool configured[kMaxDevices] = {};
+      if (lds_optin_needed(configured))
+        (void)hipFuncSetAttribute((const void*)conv_k3_r8_kernel<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((conv_k3_r8_kernel<NQ>), dim3((unsigned)mt8, (unsigned)nch, (unsigned)c.N), dim3(512), lds, s, a, w_bytes);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_lean (8-row tiles) launch failed: %s", hipGetErrorString(e));
+      return 1;
+    }
   }
   if (c.K != 1 || c.prologue != PRO_NONE || c.stats_out || !c.w16) return 0;
   if (c.epilogue != EPI_STORE && c.epilogue != EPI_RSUB && c.epilogue != EPI_WN_RES_SKIP && c.epilogue != EPI_WN_SKIP_LAST) return 0;

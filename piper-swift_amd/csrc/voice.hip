@@ -164,6 +164,7 @@ struct ConvW {  // one resident conv: packed (MFMA) or raw (direct) weights + bi
   const float* w = nullptr;
   const float* w16 = nullptr;  // 16-wide fragment image (short-utterance geometry)
   const float* w16g = nullptr; // the same for a gated conv: 8 tanh rows + their 8 sigmoid rows per tile
+  const float* w8 = nullptr;   // 8-row fragment image (the FFN's second conv: 768 → 192)
   const float* w4 = nullptr;   // conv_win_kernel fragment image (generator convs: long rows)
   const float* w5 = nullptr;   // conv_pipe_kernel fragment image (chunk-major step order; Cin % 32 == 0)
   const float* bias = nullptr;
@@ -331,7 +332,7 @@ struct Packer {  // bump allocator over the packed-weights allocation
 };
 
 // Registers one conv. dry = true only measures the packed size.
-ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true, bool win = false, bool gated = false) {
+ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int Cin, int K, bool has_bias = true, bool win = false, bool gated = false, bool rows8 = false) {
   ConvW c;
   c.Cout = Cout; c.Cin = Cin; c.K = K;
   c.mfma = conv_mfma_eligible(Cout, Cin, K, 1, 1);
@@ -344,6 +345,11 @@ ConvW make_conv(Packer& pk, bool dry, const std::string& prefix, int Cout, int C
     float* p16 = pk.take(packed_conv_floats(Cout, Cin, K, 16));
     if (!dry) pack_conv_weights(pk.s, w, Cout, Cin, K, p16, 16);
     c.w16 = p16;
+    if (rows8 && Cin % 32 == 0) {  // 8-row tiles for a conv with many input channels and few output rows (conv_lean.hip)
+      float* p8 = pk.take(packed_conv_rows8_floats(Cout, Cin, K));
+      if (!dry) pack_conv_weights_rows8(pk.s, w, Cout, Cin, K, p8);
+      c.w8 = p8;
+    }
     if (gated && Cout % 16 == 0) {  // tanh / sigmoid rows interleaved per 16-row tile (conv_short.hip)
       float* pg = pk.take(packed_conv_floats(Cout, Cin, K, 16));
       if (!dry) pack_conv_weights_gate16(pk.s, w, Cout, Cin, K, pg);
@@ -395,7 +401,7 @@ int compile_weights(piper_hip_voice* v, Packer& pk, bool dry, const std::vector<
     snprintf(nm, sizeof nm, "enc_p.encoder.ffn_layers.%d.conv_1", l);
     L.f1 = make_conv(pk, dry, nm, c.ffn, H, c.ffn_kernel);
     snprintf(nm, sizeof nm, "enc_p.encoder.ffn_layers.%d.conv_2", l);
-    L.f2 = make_conv(pk, dry, nm, H, c.ffn, c.ffn_kernel);
+    L.f2 = make_conv(pk, dry, nm, H, c.ffn, c.ffn_kernel, true, false, false, true);
     if (!dry) {
       snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.emb_rel_k", l); L.ek = tensor(v, nm);
       snprintf(nm, sizeof nm, "enc_p.encoder.attn_layers.%d.emb_rel_v", l); L.ev = tensor(v, nm);
@@ -556,6 +562,7 @@ void add_conv(piper_hip_voice* v, Slot& s, const std::string& name, const ConvW&
   a.w = w.w;
   a.w16 = w.w16;
   a.w16g = w.w16g;
+  a.w8 = w.w8;
   a.bias = w.bias;
   a.Cin = w.Cin; a.Cout = w.Cout; a.K = w.K;
   piper_hip_ctx* ctx = v->ctx;
