@@ -389,6 +389,20 @@ def main():
             e2p.append((time.perf_counter() - a) * 1e3)
         out["end_to_end_predicted_durations"] = {"ms": round(float(np.median(e2p)), 4), "samples": int(au.size),
                                                  "note": "duration predictor + device RandomNormalLike; no host-supplied tensors but the ids"}
+        # the same without the host round trip between the predictor and the flow: the caller bounds the frames (here 3 per id, the
+        # plan the headline runs), generate_path runs on the device, the lengths come back with the waveform
+        bound = 3 * len(ids)
+        rt.prepare(1, ids, None, None, 0.667, noise_mode="device", dp_noise=dpn, max_frames=bound)
+        rt.launch(1); rt.collect(1)
+        e2b = []
+        for _ in range(min(20, args.steps)):
+            a = time.perf_counter()
+            rt.prepare(1, ids, None, None, 0.667, noise_mode="device", dp_noise=dpn, max_frames=bound)
+            rt.launch(1)
+            ab = rt.collect(1)
+            e2b.append((time.perf_counter() - a) * 1e3)
+        out["end_to_end_predicted_durations"]["bounded"] = {"ms": round(float(np.median(e2b)), 4), "samples": int(ab.size), "max_frames": bound,
+            "note": "piper_hip_voice_prepare_batch_bounded: one stream, no synchronisation before collect; plan = bucket(max_frames)"}
     # ---- a server's view: 200 requests of mixed length, one after the other on one slot id — ids, durations and noise
     # on the HOST → audio on the HOST. Lengths are seeded draws (14 … 400 ids, 1 … 5 frames per id), so requests land in many (T, F)
     # buckets: a bucket's first request builds its plan (schedule + arena, ≈ 0.5 ms) and runs eagerly, later ones replay the graph.

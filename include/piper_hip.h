@@ -427,6 +427,15 @@ int piper_hip_voice_prepare(piper_hip_voice* v, const piper_hip_utterance* u, in
  * it would be alone, and tiles entirely past an item's end cost (almost) nothing. Group items of similar length to limit the
  * padding. `collect` returns the n waveforms back to back, each at its own length. */
 int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot);
+/* The same for utterances whose durations are to be PREDICTED (durations = noise = NULL), without the host round trip
+ * prepare_batch makes between the duration predictor and the rest (it needs the frame count to pick the plan): the caller states an upper
+ * bound on the frames per item, the plan is the bucket of `max_frames`, and the frame counts stay on the device — generate_path
+ * (the exported graph's CumSum / Less chain, GraphExecutor.swift:1283-1330 CumSum) runs there too and every kernel masks by its result, so
+ * the waveform is what prepare_batch would have produced. Nothing waits for the GPU here. Until `collect`,
+ * piper_hip_voice_prepared_samples reports the CAPACITY (n · bucket(max_frames) · hop) — the room `collect` needs — and afterwards the
+ * true lengths; piper_hip_voice_durations answers after `collect`. An item whose prediction exceeds `max_frames` makes `collect` fail
+ * with PIPER_HIP_ERR_SHAPE (prepare it again with a larger bound or through prepare_batch). */
+int piper_hip_voice_prepare_batch_bounded(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot, int max_frames);
 /* Plans (schedule + arena + HIP graph) are cached per voice by bucket — phonemes rounded up to 16, frames to 16 (64 beyond
  * 1024) — and batch size, least recently used first out, so a (T, F) never seen before usually finds its graph ready and
  * `prepare` is only the input upload ("warm"); a new bucket pays schedule construction + one validation pass + capture +

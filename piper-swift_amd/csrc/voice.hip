@@ -198,6 +198,10 @@ struct Slot {
   int32_t* dp_dur = nullptr;   // [NB][T] predicted frames per id
   std::vector<int32_t> h_dur;  // predicted durations of the attached request, per item back to back (host)
   int* h_lens = nullptr;       // pinned staging [2·NB]
+  // kind 3 prepared by piper_hip_voice_prepare_batch_bounded: the frame counts are decided on the device and reach the host with the
+  // waveform (collect). Until then h_F holds the bucket's capacity.
+  bool bounded_pending = false;
+  int bounded_cap = 0;         // max_frames the caller allowed
   hipEvent_t ev_in = nullptr;  // kind 3: "the copy of the predictor plan's projection has been read" (that plan's stream waits for it)
   float* stats = nullptr;      // [NB][2·inter][T] encoder projection (m_p ; logs_p): output of kinds 0 / 2, INPUT of kind 3
   float* h_audio = nullptr;    // pinned landing buffer of the waveform (collect: device → pinned DMA, then a host memcpy)
@@ -301,8 +305,13 @@ struct piper_hip_voice {
   struct Staging {
     int64_t* h_ids = nullptr; int32_t* h_f2i = nullptr; int* h_lens = nullptr; float* h_audio = nullptr;
     size_t cap_t = 0, cap_f = 0, cap_lens = 0, audio_cap = 0;
+    // bounded prepare (durations predicted, no host round trip): scalars of the request, the predictor's noise, and what the device reports
+    // back (frames per item, durations) — the last two written by a kernel through the host mapping
+    char* h_misc = nullptr; float* h_dpn = nullptr; int32_t* h_res = nullptr;
+    size_t cap_misc = 0, cap_dpn = 0, cap_res = 0;
   } staging[kMaxSlots];
   Slot* attached[kMaxSlots] = {};
+  Slot* attached_dp[kMaxSlots] = {};  // bounded prepare: the encoder + predictor plan this slot id holds until its next prepare / detach
   uint64_t use_clock = 0;
   int hop = 1;
 };
@@ -1869,6 +1878,9 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
     if (sg.h_f2i) (void)hipHostFree(sg.h_f2i);
     if (sg.h_lens) (void)hipHostFree(sg.h_lens);
     if (sg.h_audio) (void)hipHostFree(sg.h_audio);
+    if (sg.h_misc) (void)hipHostFree(sg.h_misc);
+    if (sg.h_dpn) (void)hipHostFree(sg.h_dpn);
+    if (sg.h_res) (void)hipHostFree(sg.h_res);
   }
   for (auto& st : v->free_sets) {
     for (hipEvent_t e : {st.ev0, st.ev1, st.ev_fork, st.ev_join[0], st.ev_join[1]})
@@ -1921,22 +1933,25 @@ void evict_idle_plans(piper_hip_voice* v) {
 // Run a plan once on its stream. A plan that has a graph replays it; a freshly built one runs its schedule eagerly (the answer of
 // the request that missed the cache) and captures + instantiates the graph behind that run, so that the next request of the bucket
 // replays. The capture enqueues nothing; it and the instantiate are host work that overlaps the eager pass on the GPU.
-int launch_plan(piper_hip_voice* v, Slot& s) {
+// `on`: the stream the plan runs on (default: its own). A plan without parallel lanes may run on any stream — the bounded prepare puts
+// the predictor plan on the stream of the plan that continues from it, so the two need no event between them.
+int launch_plan(piper_hip_voice* v, Slot& s, hipStream_t on = nullptr) {
+  const hipStream_t q = on ? on : s.stream;
   if (s.exec) {
-    PH_HIP(hipGraphLaunch(s.exec, s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(hipGraphLaunch(s.exec, q), PIPER_HIP_ERR_LAUNCH);
     return PIPER_HIP_OK;
   }
-  int rc = run_schedule(s, s.stream, false);
+  int rc = run_schedule(s, q, false);
   if (rc) return rc;
   using clk = std::chrono::steady_clock;
   const auto t0 = clk::now();
-  hipError_t e = hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal);
+  hipError_t e = hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "plan: begin capture failed: %s", hipGetErrorString(e));
   // fp32 generator: parallel ResBlock branches measured SLOWER on hipGraph (fork/join edges cost more than the three
   // short kernels gain), so that graph stays a single chain unless asked otherwise. The bf16 generator's builder decides
   // for itself (s.parallel).
-  rc = run_schedule(s, s.stream, s.parallel);
-  hipError_t ce = hipStreamEndCapture(s.stream, &s.graph);
+  rc = run_schedule(s, q, s.parallel && !on);
+  hipError_t ce = hipStreamEndCapture(q, &s.graph);
   if (rc) return rc;
   if (ce != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "plan: graph capture failed: %s", hipGetErrorString(ce));
   const auto t1 = clk::now();
@@ -2006,7 +2021,12 @@ void detach(piper_hip_voice* v, int slot) {
   if (p->stream) (void)hipStreamSynchronize(p->stream);  // its last launch may still be running / reading the inputs
   p->in_use = false;
   p->st_next = -1;
+  p->bounded_pending = false;
   v->attached[slot] = nullptr;
+  if (v->attached_dp[slot]) {  // ran on p's stream (bounded prepare): idle now
+    v->attached_dp[slot]->in_use = false;
+    v->attached_dp[slot] = nullptr;
+  }
   // An idle plan needs no stream: hand the set to the next plan that is attached (usually the one replacing this plan on the same
   // slot id), so that after a slot id's first request no prepare ever creates a stream again (≈ 3 ms each, r3).
   if (p->inited && p->stream) {
@@ -2095,6 +2115,8 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   s.last_use = ++v->use_clock;
   // the previous launch on this plan may still be reading the inputs
   PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  s.bounded_pending = false;
+  if (v->attached_dp[slot]) { v->attached_dp[slot]->in_use = false; v->attached_dp[slot] = nullptr; }
   if (kind == 3)  // the predictor's plan has finished (predict synchronises): its projection becomes this plan's input
   {
     PH_HIP(hipMemcpyAsync(s.stats, dp_plan->stats, (size_t)n * 2 * I * T * sizeof(float), hipMemcpyDeviceToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
@@ -2168,6 +2190,207 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   s.timed = false;
   return slot;
 }
+
+namespace {
+// generate_path on the device (GraphExecutor runs the exported graph's CumSum / Less / Cast chain): per item, frames per id → the frame
+// count (Piper: clamp_min(Σ w_ceil, 1)), clamped to the plan's capacity, and the id every frame belongs to. One block per item; the
+// cumulative sums live in LDS (T ≤ 4096), every frame finds its id by bisection. `rep` (host-mapped, may be null) receives
+// [n] predicted frame counts BEFORE clamping, then the items' durations at rep + n + b·T.
+__global__ __launch_bounds__(256) void dp_paths_kernel(const int32_t* __restrict__ dur, const int* __restrict__ lensT, int T, int F, int cap,
+                                                        int32_t* __restrict__ frame2id, int* __restrict__ lensF, int32_t* __restrict__ rep, int n) {
+  __shared__ int cum[4096];
+  __shared__ int part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Tb = min(lensT[b], T);
+  const int per = (T + 255) / 256;  // ids per thread, consecutive
+  const int t0 = tid * per;
+  int sum = 0;
+  for (int i = 0; i < per; i++) {
+    const int t = t0 + i;
+    const int d = t < Tb ? max(dur[(size_t)b * T + t], 0) : 0;
+    if (rep && t < T) rep[n + (size_t)b * T + t] = d;
+    sum += d;
+    if (t < T) cum[t] = sum;  // within the thread's run
+  }
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive scan of the per-thread sums
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int base = tid ? part[tid - 1] : 0;
+  for (int i = 0; i < per; i++)
+    if (t0 + i < T) cum[t0 + i] += base;
+  __syncthreads();
+  const int total = part[255];
+  const int want = max(total, 1);          // an all-zero prediction still yields one frame (of id 0)
+  const int Fv = min(min(want, cap), F);
+  if (tid == 0) {
+    lensF[b] = Fv;
+    if (rep) { rep[b] = want; if (total < 1) rep[n + (size_t)b * T] = 1; }
+  }
+  for (int f = tid; f < F; f += 256) {
+    int id = 0;
+    if (f < Fv && f < total) {  // smallest t with cum[t] > f
+      int lo = 0, hi = Tb - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] > f) hi = mid; else lo = mid + 1;
+      }
+      id = lo;
+    }
+    frame2id[(size_t)b * F + f] = id;
+  }
+}
+
+template <typename Tp>
+int grow_pinned(Tp*& p, size_t& cap, size_t need) {
+  if (cap >= need) return PIPER_HIP_OK;
+  if (p) (void)hipHostFree(p);
+  p = nullptr; cap = 0;
+  size_t c = 1024;
+  while (c < need) c <<= 1;
+  PH_HIP(hipHostMalloc((void**)&p, c * sizeof(Tp)), PIPER_HIP_ERR_ALLOC);
+  cap = c;
+  return PIPER_HIP_OK;
+}
+}  // namespace
+
+// Whole utterances with PREDICTED durations and no host round trip between the predictor and the rest: the caller states an upper bound on
+// the frames per item; the plan is the bucket of that bound and every kernel masks by the frame count the device decides. One stream carries
+// uploads → encoder + predictor → generate_path (dp_paths_kernel) → flow + generator; the host learns the lengths with the waveform (collect).
+PH_EXPORT int piper_hip_voice_prepare_batch_bounded(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot, int max_frames) {
+  if (!v || !utts) PH_FAIL(PIPER_HIP_ERR_ARG, "null argument");
+  if (n < 1 || n > 256) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch size %d outside [1,256]", n);
+  if (slot < 0 || slot >= kMaxSlots) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d out of range [0,%d)", slot, kMaxSlots);
+  if (max_frames < 1 || (int64_t)max_frames * std::max(v->hop, 1) > 0x3fffffff / 64) PH_FAIL(PIPER_HIP_ERR_SHAPE, "prepare_batch_bounded: max_frames %d out of range", max_frames);
+  if (!v->cfg.dp_present) PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "voice has no duration predictor (dp_present = 0): supply durations");
+  int Tmax = 0;
+  for (int b = 0; b < n; b++) {
+    const piper_hip_utterance& u = utts[b];
+    if (!u.phoneme_ids) PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: null ids", b);
+    if (u.t < 1 || u.t > 4096) PH_FAIL(PIPER_HIP_ERR_SHAPE, "utterance %d: %d ids outside [1,4096]", b, u.t);
+    if (u.durations || u.noise)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: prepare_batch_bounded predicts the durations and cannot take a host noise tensor (its shape depends "
+                                 "on them): pass durations = noise = NULL (noise_mode DEVICE draws it on the device)", b);
+    if (u.noise_mode != PIPER_HIP_NOISE_INJECTED && u.noise_mode != PIPER_HIP_NOISE_DEVICE)
+      PH_FAIL(PIPER_HIP_ERR_ARG, "utterance %d: unknown noise_mode %d", b, u.noise_mode);
+    Tmax = std::max(Tmax, u.t);
+  }
+  const int T = bucket_t(Tmax), F = bucket_f(max_frames), I = v->cfg.inter;
+  if ((int64_t)F * v->hop * n > 0x3fffffff) PH_FAIL(PIPER_HIP_ERR_SHAPE, "batch too large");
+  PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  int rc;
+  Slot* cur = v->attached[slot];
+  const bool same = cur && cur->built && cur->kind == 3 && cur->T == T && cur->F == F && cur->NB == n && cur->prec == v->precision;
+  if (cur && !same) detach(v, slot);
+  if (!same) {
+    bool built = false;
+    if ((rc = acquire_plan(v, 3, T, F, n, &cur, &built))) return rc;
+    cur->in_use = true;
+    v->attached[slot] = cur;
+  }
+  Slot& s = *cur;
+  s.last_use = ++v->use_clock;
+  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // the previous request of this slot id: its staging and its predictor plan are idle now
+  Slot* dp = v->attached_dp[slot];
+  if (dp && !(dp->built && dp->T == T && dp->NB == n && dp->prec == v->precision)) { dp->in_use = false; dp = v->attached_dp[slot] = nullptr; }
+  if (!dp) {
+    bool built = false;
+    if ((rc = acquire_plan(v, 2, T, 16, n, &dp, &built))) return rc;
+    dp->in_use = true;
+    v->attached_dp[slot] = dp;
+  }
+  dp->last_use = s.last_use;
+  evict_idle_plans(v);
+  auto& sg = v->staging[slot];
+  const size_t misc_bytes = (size_t)n * (sizeof(int) + 2 * sizeof(unsigned) + sizeof(float)) + dp_scalars_bytes(n);
+  if ((rc = grow_pinned(sg.h_ids, sg.cap_t, (size_t)T * n)) || (rc = grow_pinned(sg.h_misc, sg.cap_misc, misc_bytes)) ||
+      (rc = grow_pinned(sg.h_dpn, sg.cap_dpn, (size_t)n * 2 * T)) || (rc = grow_pinned(sg.h_res, sg.cap_res, (size_t)n + (size_t)n * T)))
+    return rc;
+  int* h_lens = (int*)sg.h_misc;
+  unsigned* h_rng = (unsigned*)(h_lens + n);
+  float* h_ns = (float*)(h_rng + 2 * n);
+  char* h_sc = (char*)(h_ns + n);
+  bool any_noise = false;
+  for (int b = 0; b < n; b++) {
+    const piper_hip_utterance& u = utts[b];
+    memcpy(sg.h_ids + (size_t)b * T, u.phoneme_ids, (size_t)u.t * sizeof(int64_t));
+    for (int t = u.t; t < T; t++) sg.h_ids[(size_t)b * T + t] = 0;
+    h_lens[b] = u.t;
+    const bool dev = u.noise_mode == PIPER_HIP_NOISE_DEVICE;
+    h_rng[2 * b] = dev ? 1u : 0u;
+    h_rng[2 * b + 1] = u.seed;
+    h_ns[b] = u.noise_scale;
+    for (int r = 0; r < 2; r++) {
+      float* row = sg.h_dpn + ((size_t)b * 2 + r) * T;
+      if (u.dp_noise) { memcpy(row, u.dp_noise + (size_t)r * u.t, (size_t)u.t * sizeof(float)); any_noise = true; }
+      for (int t = u.dp_noise ? u.t : 0; t < T; t++) row[t] = 0.0f;
+    }
+    dp_scalars_fill(h_sc, b, u.noise_w, u.length_scale == 0.0f ? 1.0f : u.length_scale, (!u.dp_noise && dev) ? 1u : 0u, u.seed);
+    sg.h_res[b] = -1;
+  }
+  (void)any_noise;
+  const hipStream_t q = s.stream;
+  PH_HIP(hipMemcpyAsync(dp->ids, sg.h_ids, (size_t)n * T * sizeof(int64_t), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(dp->lensT, h_lens, (size_t)n * sizeof(int), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(dp->dp_noise, sg.h_dpn, (size_t)n * 2 * T * sizeof(float), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(dp->dp_scalars, h_sc, dp_scalars_bytes(n), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.lensT, h_lens, (size_t)n * sizeof(int), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.rng, h_rng, 2 * (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.noise_scale, h_ns, (size_t)n * sizeof(float), hipMemcpyHostToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  for (int b = 0; b < n; b++)  // INJECTED without a tensor = zero noise, as in prepare_batch
+    if (!h_rng[2 * b]) PH_HIP(hipMemsetAsync(s.noise + (size_t)b * I * F, 0, (size_t)I * F * sizeof(float), q), PIPER_HIP_ERR_LAUNCH);
+  if ((rc = launch_plan(v, *dp, q))) return rc;
+  PH_HIP(hipMemcpyAsync(s.stats, dp->stats, (size_t)n * 2 * I * T * sizeof(float), hipMemcpyDeviceToDevice, q), PIPER_HIP_ERR_LAUNCH);
+  int32_t* rep = nullptr;
+  if (hipHostGetDevicePointer((void**)&rep, sg.h_res, 0) != hipSuccess) { rep = nullptr; (void)hipGetLastError(); }
+  if (!rep) PH_FAIL(PIPER_HIP_ERR_UNAVAILABLE, "prepare_batch_bounded: page-locked memory has no device mapping on this system");
+  hipLaunchKernelGGL(dp_paths_kernel, dim3(n), dim3(256), 0, q, dp->dp_dur, dp->lensT, T, F, std::min(max_frames, F), s.frame2id, s.lensF, rep, n);
+  PH_HIP(hipGetLastError(), PIPER_HIP_ERR_LAUNCH);
+  s.st_next = -1;
+  s.h_T.assign(n, 0);
+  for (int b = 0; b < n; b++) s.h_T[b] = utts[b].t;
+  s.h_F.assign(n, F);  // capacity until collect has the device's answer
+  s.h_dur.clear();
+  s.bounded_pending = true;
+  s.bounded_cap = std::min(max_frames, F);
+  s.timed = false;
+  return slot;
+}
+
+namespace {
+// after the slot's stream has been synchronised: the device's frame counts and durations → h_F / h_dur; an item over the bound is an error
+int bounded_finish(piper_hip_voice* v, int slot, Slot& s) {
+  const auto& sg = v->staging[slot];
+  s.bounded_pending = false;
+  s.h_dur.clear();
+  int over = -1;
+  for (int b = 0; b < s.NB; b++) {
+    const int want = sg.h_res[b];
+    if (want < 1) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "bounded utterance %d: the device reported no frame count (was the slot launched?)", b);
+    if (want > s.bounded_cap && over < 0) over = b;
+    s.h_F[b] = std::min(want, s.bounded_cap);
+    const int32_t* d = sg.h_res + s.NB + (size_t)b * s.T;
+    s.h_dur.insert(s.h_dur.end(), d, d + s.h_T[b]);
+  }
+  if (over >= 0)
+    PH_FAIL(PIPER_HIP_ERR_SHAPE, "bounded utterance %d: the predictor wants %d frames, the caller allowed %d — prepare it again with a larger bound "
+                                 "(or without one)", over, sg.h_res[over], s.bounded_cap);
+  return PIPER_HIP_OK;
+}
+
+// item b of a bounded slot → page-locked host memory at its bucket offset; the length comes from device memory
+__global__ __launch_bounds__(256) void copy_out_len_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ lensF, int b, int hop) {
+  const int64_t n = (int64_t)lensF[b] * hop;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  const int64_t n4 = n >> 2;  // hop·F·4 bytes: rows are 16-byte aligned when hop % 4 == 0 (checked by the caller)
+  for (int64_t i = tid; i < n4; i += nth) ((float4*)dst)[i] = ((const float4*)src)[i];
+  for (int64_t i = (n4 << 2) + tid; i < n; i += nth) dst[i] = src[i];
+}
+}  // namespace
 
 namespace {
 int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out, int max_entries, Slot** plan_out);
@@ -2340,6 +2563,48 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
   if (!p) PH_FAIL(PIPER_HIP_ERR_ARG, "slot %d is not prepared", slot);
   PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
   Slot& s = *p;
+  if (s.bounded_pending) {
+    // lengths still on the device. Short buckets: the waveform rows go to the slot id's page-locked buffer at bucket stride by a kernel that
+    // reads each length from device memory — ONE synchronisation for lengths and samples; long ones: synchronise, then the usual copy.
+    const int64_t row = (int64_t)s.F * v->hop;
+    const size_t ub = (size_t)row * s.NB * sizeof(float);
+    if (host_audio && max_samples < row * s.NB)
+      PH_FAIL(PIPER_HIP_ERR_SHAPE, "collect: a bounded slot needs room for its capacity (%lld samples: piper_hip_voice_prepared_samples before collect), got %lld",
+              (long long)(row * s.NB), (long long)max_samples);
+    auto& sg = v->staging[slot];
+    float* dst_dev = nullptr;
+    if (host_audio && ub <= ((size_t)1 << 20) && (v->hop & 3) == 0) {
+      if (sg.audio_cap < ub) {
+        if (sg.h_audio) (void)hipHostFree(sg.h_audio);
+        sg.h_audio = nullptr; sg.audio_cap = 0;
+        size_t c = 65536;
+        while (c < ub) c <<= 1;
+        if (hipHostMalloc((void**)&sg.h_audio, c) == hipSuccess) sg.audio_cap = c;
+        else { sg.h_audio = nullptr; (void)hipGetLastError(); }
+      }
+      if (sg.h_audio && hipHostGetDevicePointer((void**)&dst_dev, sg.h_audio, 0) != hipSuccess) { dst_dev = nullptr; (void)hipGetLastError(); }
+    }
+    if (dst_dev) {
+      for (int b = 0; b < s.NB; b++) {
+        const int blocks = (int)std::min<int64_t>((row + 4 * 256 - 1) / (4 * 256), 1024);
+        hipLaunchKernelGGL(copy_out_len_kernel, dim3(blocks), dim3(256), 0, s.stream, s.audio + (int64_t)b * s.n_samples, dst_dev + (int64_t)b * row, s.lensF, b, v->hop);
+        PH_HIP(hipGetLastError(), PIPER_HIP_ERR_LAUNCH);
+      }
+    }
+    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    const int frc = bounded_finish(v, slot, s);
+    if (frc) return frc;
+    if (dst_dev) {
+      int64_t off = 0;
+      for (int b = 0; b < s.NB; b++) {
+        const int64_t nb = (int64_t)s.h_F[b] * v->hop;
+        memcpy(host_audio + off, sg.h_audio + (int64_t)b * row, (size_t)nb * sizeof(float));
+        off += nb;
+      }
+      return PIPER_HIP_OK;
+    }
+    // fall through: the lengths are known now
+  }
   if (host_audio) {
     int64_t total = 0;  // batch items back to back, each at its own true length
     for (int b = 0; b < s.NB; b++) total += (int64_t)s.h_F[b] * v->hop;

@@ -216,6 +216,7 @@ _PROTOS = {
     "piper_hip_voice_prepared_samples": (C.c_int, [c_vp, C.c_int, c_i64p, C.c_int, c_i64p]),
     "piper_hip_voice_durations": (C.c_int, [c_vp, C.c_int, c_i32p, C.c_int, C.POINTER(C.c_int)]),
     "piper_hip_voice_prepare_batch": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int]),
+    "piper_hip_voice_prepare_batch_bounded": (C.c_int, [c_vp, C.POINTER(Utterance), C.c_int, C.c_int, C.c_int]),
     "piper_hip_voice_batch_size": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_plan_info": (C.c_int, [c_vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                             C.POINTER(C.c_size_t)]),
@@ -833,15 +834,45 @@ class HipRuntime:
         return self.collect(0)
 
     def prepare(self, slot, phonemeIDs, durations=None, noise=None, noiseScale=0.667, noise_mode="injected", seed=1234, length_scale=1.0,
-                noise_w=0.8, dp_noise=None):
+                noise_w=0.8, dp_noise=None, max_frames=None):
+        """max_frames (durations must be None): predicted durations WITHOUT the host round trip — the plan is the bucket of that bound and the
+        frame count stays on the device until collect (piper_hip_voice_prepare_batch_bounded)."""
         u, k = self._utt(phonemeIDs, durations, noise, noiseScale, noise_mode, seed, length_scale, noise_w, dp_noise)
-        rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
+        if max_frames is not None:
+            rc = self.lib.piper_hip_voice_prepare_batch_bounded(self.voice, C.byref(u), 1, slot, int(max_frames))
+        else:
+            rc = self.lib.piper_hip_voice_prepare(self.voice, C.byref(u), slot)
         if rc < 0:
             _check(rc)
         tot = C.c_int64()
         _check(self.lib.piper_hip_voice_prepared_samples(self.voice, slot, None, 0, C.byref(tot)))
-        self._keep[slot] = (k, int(tot.value))
+        self._keep[slot] = (k, int(tot.value), max_frames is not None)
         return rc
+
+    def prepare_batch_bounded(self, slot, utterances, max_frames, noiseScale=0.667, noise_mode="device", seed=1234, length_scale=1.0, noise_w=0.8):
+        """utterances: list of (phonemeIDs, dp_noise-or-None); durations predicted on the device, at most max_frames frames per item."""
+        n = len(utterances)
+        arr = (Utterance * n)()
+        keep = []
+        for i, (ids, dpn) in enumerate(utterances):
+            u, k = self._utt(ids, None, None, noiseScale, noise_mode, seed, length_scale, noise_w, dpn)
+            arr[i] = u
+            keep.append(k)
+        rc = self.lib.piper_hip_voice_prepare_batch_bounded(self.voice, arr, n, slot, int(max_frames))
+        if rc < 0:
+            _check(rc)
+        tot = C.c_int64()
+        _check(self.lib.piper_hip_voice_prepared_samples(self.voice, slot, None, 0, C.byref(tot)))
+        self._keep[slot] = (keep, int(tot.value), True)
+        return rc
+
+    def prepared_samples(self, slot):
+        """samples per batch item of the slot (a bounded slot: its capacity before collect, the true lengths after)."""
+        nb = self.lib.piper_hip_voice_batch_size(self.voice, slot)
+        per = (C.c_int64 * max(nb, 1))()
+        tot = C.c_int64()
+        _check(self.lib.piper_hip_voice_prepared_samples(self.voice, slot, per, nb, C.byref(tot)))
+        return [int(x) for x in per[:nb]], int(tot.value)
 
     def durations(self, slot):
         """Frames per id the prepared slot uses (supplied or predicted), items back to back."""
@@ -935,6 +966,9 @@ class HipRuntime:
             out = np.empty(max(n, 1), np.float32)
         assert out.dtype == np.float32 and out.size >= n and out.flags.c_contiguous
         _check(self.lib.piper_hip_voice_collect(self.voice, slot, out.ctypes.data_as(c_f32p), n))
+        if len(self._keep[slot]) > 2 and self._keep[slot][2]:  # bounded: n was the capacity; the true lengths are known now
+            n = self.prepared_samples(slot)[1]
+            self._keep[slot] = (self._keep[slot][0], n, False)
         return out[:n]
 
     def tap(self, slot, name, max_floats):

@@ -176,6 +176,87 @@ def test_batch_mixes_supplied_and_predicted_durations(rts, voices):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("quality", ["medium", "high"])
+def test_bounded_prepare_matches_the_two_step_path_and_the_oracle(quality, rts, voices):
+    """piper_hip_voice_prepare_batch_bounded: the frame count never visits the host between the predictor and the flow — generate_path
+    runs on the device, the plan is the bucket of the caller's bound. Same waveform, durations and length as prepare(durations = NULL)
+    (which reads the durations back and picks the plan on the host) — bit for bit when both land in the same bucket; and against the oracle."""
+    cfg, blob = voices[quality]
+    rt = rts[quality]
+    ids = kd.FIXTURE_IDS * 3
+    nz = kd.sym(SD + 170, (2, len(ids)), 1.7320508)
+    kw = dict(length_scale=1.2, noise_w=0.8, dp_noise=nz, noise_mode="device", seed=77)
+    rt.prepare(1, ids, None, None, 0.667, **kw)
+    rt.launch(1)
+    two_step = rt.collect(1).copy()
+    dur = rt.durations(1).copy()
+    F = int(dur.sum())
+    for bound in (F, F + 37, 4 * F):  # exactly enough, another bucket, a much larger plan
+        rt.prepare(3, ids, None, None, 0.667, max_frames=bound, **kw)
+        per, cap = rt.prepared_samples(3)
+        assert cap >= F * cfg.hop and cap % cfg.hop == 0  # capacity of the bucket until collect
+        rt.launch(3)
+        audio = rt.collect(3)
+        assert audio.size == F * cfg.hop
+        assert rt.prepared_samples(3) == ([F * cfg.hop], F * cfg.hop)
+        assert np.array_equal(rt.durations(3), dur)
+        if bound == F:  # the same bucket as the two-step path: the same kernels in the same order
+            assert np.array_equal(audio, two_step), (bound, np.abs(audio - two_step).max())
+        else:  # a larger bucket may pick other kernels (tile shapes follow the row length): same values up to summation order
+            assert_close(audio, two_step, WAVE_TOL, f"{quality}: bound {bound} vs two-step")
+    noise = orc.random_normal_like(cfg.inter * F, 77).reshape(cfg.inter, F)
+    ref = orc.synthesize(cfg, blob, ids, dur.tolist(), noise, 0.667)
+    assert_close(two_step, ref, WAVE_TOL, f"{quality}: bounded prepare")
+
+
+@pytest.mark.gpu
+def test_bounded_prepare_ragged_batch_zero_noise_and_replay(rts, voices):
+    cfg, blob = voices["medium"]
+    rt = rts["medium"]
+    ids_a, ids_b = kd.FIXTURE_IDS * 4, kd.FIXTURE_IDS
+    na, nb = kd.sym(SD + 171, (2, len(ids_a)), 1.7320508), kd.sym(SD + 172, (2, len(ids_b)), 1.7320508)
+    (da, _), (db, _) = rt.predict_durations([(ids_a, na), (ids_b, nb)], noise_w=0.8)
+    Fa, Fb = int(da.sum()), int(db.sum())
+    for rep in range(2):  # the second pass replays both captured graphs on the same plans
+        rt.prepare_batch_bounded(4, [(ids_a, na), (ids_b, nb)], max(Fa, Fb) + 5, noise_mode="injected")  # injected + no tensor = zero z noise
+        rt.launch(4)
+        audio = rt.collect(4)
+        assert rt.prepared_samples(4)[0] == [Fa * cfg.hop, Fb * cfg.hop]
+        assert np.array_equal(rt.durations(4), np.concatenate([da, db]))
+        assert audio.size == (Fa + Fb) * cfg.hop
+        assert_close(audio[:Fa * cfg.hop], orc.synthesize(cfg, blob, ids_a, da.tolist(), np.zeros((cfg.inter, Fa), np.float32), 0.667), WAVE_TOL, f"item a, pass {rep}")
+        assert_close(audio[Fa * cfg.hop:], orc.synthesize(cfg, blob, ids_b, db.tolist(), np.zeros((cfg.inter, Fb), np.float32), 0.667), WAVE_TOL, f"item b, pass {rep}")
+    # a supplied-durations request on the same slot id afterwards (the slot gives the predictor plan back)
+    dur = [2] * len(ids_b)
+    nzb = kd.sym(SD + 173, (cfg.inter, sum(dur)), 1.7320508)
+    rt.prepare(4, ids_b, dur, nzb, 0.667)
+    rt.launch(4)
+    assert_close(rt.collect(4), orc.synthesize(cfg, blob, ids_b, dur, nzb, 0.667), WAVE_TOL, "supplied durations after a bounded request")
+
+
+@pytest.mark.gpu
+def test_bounded_prepare_reports_a_prediction_over_the_bound(rts, voices):
+    cfg, _ = voices["medium"]
+    rt = rts["medium"]
+    ids = kd.FIXTURE_IDS * 2
+    nz = kd.sym(SD + 174, (2, len(ids)), 1.7320508)
+    (d, _), = rt.predict_durations([(ids, nz)], noise_w=0.8)
+    F = int(d.sum())
+    assert F > 8
+    rt.prepare(5, ids, None, None, 0.667, dp_noise=nz, noise_mode="device", max_frames=F - 3)
+    rt.launch(5)
+    with pytest.raises(ph.ExecutionError, match=f"wants {F} frames"):
+        rt.collect(5)
+    rt.prepare(5, ids, None, None, 0.667, dp_noise=nz, noise_mode="device", max_frames=F)  # the slot is usable again
+    rt.launch(5)
+    assert rt.collect(5).size == F * cfg.hop
+    with pytest.raises(ph.ExecutionError, match="predicts the durations"):
+        rt.prepare(5, ids, [1] * len(ids), None, 0.667, max_frames=64)
+    with pytest.raises(ph.ExecutionError, match="max_frames"):
+        rt.prepare(5, ids, None, None, 0.667, max_frames=0)
+
+
+@pytest.mark.gpu
 def test_voice_without_predictor_refuses(backend, voices):
     cfg, blob = voices["medium"]
     cfg2 = ph.voice_config("medium")
