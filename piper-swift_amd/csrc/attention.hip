@@ -670,6 +670,13 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     const float qv = qb[(int64_t)c * T + min(i0 + i, Tv - 1)];
     qs[c * 16 + i] = ok ? qv / scale : 0.0f;
   }
+  // relative-value fragments of phase 3: requested here, with everything else of the block's first round trip (asked for where they are
+  // used they cost the launch a cold round trip of their own after the softmax)
+  float arel[4];
+  if (wave < NCT) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + wave * 16 + r16];
+  }
   // relative-key logits: wave 7 straight from global (E_k is tiny), while the others wait for the K tile
   float ekf[NS];
   if (wave == kAttWaves - 1) {
@@ -755,11 +762,6 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
   const bool pi_ok = i0 + r16 < Tv;
   const float* prow = sc + r16 * Tp;
   f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};
-  float arel[4];
-  if (wave < NCT) {
-#pragma unroll
-    for (int s = 0; s < 4; s++) arel[s] = ev[min(4 * s + kq, W - 1) * D + wave * 16 + r16];
-  }
   for (int t = 0; t < ntile; t++) {
     const int t0 = kbeg + t * kTK;
     if (t + 1 < ntile) fetch(vb, t0 + kTK);

@@ -79,16 +79,35 @@ __device__ unsigned long long* ph_win_trace_buf;
 #define PH_WSTAMP(k) do { } while (0)
 #endif
 
-// WM waves along rows × WN along columns × KS along the contraction; WM·WN·KS = 4. One 32×32 tile per wave.
+// WM waves along rows × WN along columns × KS along the contraction; WM·WN·KS = 4 or 8 waves per block. One 32×32 tile per wave.
+// The 8-wave block (round 3: 4 row tiles × 2 contraction slices of one column tile) is for plain convs with few tiles and a wide window
+// (stage 0 of the generator: 128 → 128 channels on 2 688 columns, 1 008 tiles): with 4 waves a block was ONE tile split four ways and
+// staged the whole 128-row window for itself — four times per column tile. Sharing the window is worth 1.4 … 3.6 µs of 27 … 30 there
+// (r3 A/B, tools/probe/gen_positions.py); 16 waves gave the same, and on the ConvTransposes (two taps: tiny windows) both are slower.
+// What bounds these launches is not the window: ≈ 10 µs of MFMA time when perfectly spread + one un-overlapped prologue / staging /
+// epilogue per block (every block of the single round is in the same phase at the same time).
 struct ConvWinMulti {
   ConvWinArgs c[kWinMulti];
 };
 
 template <int WM, int WN, int KS>
-__global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi, int batch) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void conv_win_kernel(const ConvWinMulti multi, int batch, int xcd_rows) {
+  constexpr int NW = WM * WN * KS, BT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float win[];  // [Cin][Wp] + dump float4; reused for the K-split reduction
   const ConvWinArgs& p = multi.c[blockIdx.z / batch];  // wave-uniform: which of the launch's convs this block works on
-  static_assert(WM * WN * KS == 4, "4 waves per block");
+  // Workgroups go to the 8 XCDs round robin by their linear id, and each XCD has its own L2. With the column tile as the fastest grid
+  // index every XCD ends up multiplying every row tile, i.e. pulls the WHOLE weight image through its L2 (the stage-0 ConvTranspose: 8 × 2 MB
+  // for 0.35 GFLOP). xcd_rows (launcher: set when the weights outweigh the activations and gridDim.y % 8 == 0) renumbers the blocks so
+  // that row-tile group y runs on XCD y mod 8: each L2 then sees one eighth of the weights and all of the (smaller) activations.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_rows) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int q = lin >> 3;
+    const int yh = __builtin_amdgcn_readfirstlane(q / (int)gridDim.x);
+    bx = q - yh * (int)gridDim.x;
+    by = (lin & 7) + 8 * yh;
+  }
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
   constexpr int NBC = WN * 32;
   PH_WSTAMP(0);
   const int lane = threadIdx.x & 63;
@@ -100,10 +119,10 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
   const int taps = ct ? p.K / p.ct_stride : p.K;
   const int C2 = p.Cin >> 1;
   const int n = blockIdx.z % batch;
-  const int nb0 = blockIdx.x * NBC;
+  const int nb0 = bx * NBC;
   // bucketed / ragged batches: every column of this block at or past the item's true length ⇒ nothing anyone reads (block-uniform)
   if (p.len_ptr && nb0 >= min(p.len_ptr[n] * p.len_mul, p.Lin)) return;
-  const int mt = blockIdx.y * WM + wm;
+  const int mt = by * WM + wm;
   const int off_min = ct ? -(taps - 1) : -p.padL;
   const int off_max = ct ? (p.ct_stride - 1 + p.ct_pad) / p.ct_stride : (p.K - 1) * p.dil - p.padL;
   const int W = NBC + off_max - off_min;
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
   // ---- stage the window: rows by wave, 256 positions (64 lanes × float4) per wave instruction
   auto stage = [&](auto avg_tag) {
     constexpr bool AVG = decltype(avg_tag)::value;
-    constexpr int kStage = AVG ? 5 : 16;  // float4 loads in flight per lane: 16, or 5 × 3 sources
+    constexpr int kStage = (AVG ? 5 : 16) * 4 / NW + (AVG && NW > 4 ? 1 : 0);  // float4 loads in flight per lane: 16, or 5 × 3 sources (4 waves)
     const int64_t xoff = (int64_t)n * p.Cin * p.Lin;
     const float* xb = p.x + xoff;
     const float* xb2 = AVG ? p.x2 + xoff : nullptr;
@@ -141,13 +160,13 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
     // 10/64 of every load instruction useful and cost 4 … 13 dependent round trips (r3s trace: 23 k … 70 k cycles of staging
     // against 9 k … 22 k of MFMAs); flat, a thread's kStage slots cover the block's window in one or two.
     const unsigned inv = 0xFFFFFFFFu / (unsigned)W4 + 1u;
-    for (int base = threadIdx.x; base < total4; base += kBT * kStage) {
+    for (int base = threadIdx.x; base < total4; base += BT * kStage) {
       float4 t[kStage], t2[AVG ? kStage : 1], t3[AVG ? kStage : 1];
       int dst[kStage];
       int nvalid[kStage];
 #pragma unroll
       for (int q = 0; q < kStage; q++) {
-        const int i = base + q * kBT;
+        const int i = base + q * BT;
         const int ic = min(i, total4 - 1);
         const int row = (int)__umulhi((unsigned)ic, inv);
         const int i4 = ic - row * W4;
@@ -293,11 +312,11 @@ __global__ __launch_bounds__(kBT) void conv_win_kernel(const ConvWinMulti multi,
 }
 
 template <int WM, int WN, int KS>
-int launch_inst(hipStream_t s, const ConvWinMulti& a, int batch, dim3 grid, size_t lds) {
+int launch_inst(hipStream_t s, const ConvWinMulti& a, int batch, dim3 grid, size_t lds, int xcd_rows) {
   static bool raised[kMaxDevices] = {};  // the opt-in is per device
   if (lds > 64 * 1024 && lds_optin_needed(raised))
     (void)hipFuncSetAttribute((const void*)conv_win_kernel<WM, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((conv_win_kernel<WM, WN, KS>), grid, dim3(kBT), lds, s, a, batch);
+  hipLaunchKernelGGL((conv_win_kernel<WM, WN, KS>), grid, dim3(64 * WM * WN * KS), lds, s, a, batch, xcd_rows);
   return PIPER_HIP_OK;
 }
 
@@ -381,13 +400,16 @@ int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* 
   while (KS > 1 && Sp_min / KS < 16) KS >>= 1;
   // candidates in order of preference: the wanted K-split first; waves along rows before columns (they then share the
   // staged window and nothing else); a single row tile (C = 32) puts the waves side by side along the columns
-  static const int cand[6][3] = {{4, 1, 1}, {2, 2, 1}, {1, 4, 1}, {2, 1, 2}, {1, 2, 2}, {1, 1, 4}};
+  static const int cand[7][3] = {{4, 1, 1}, {2, 2, 1}, {1, 4, 1}, {2, 1, 2}, {1, 2, 2}, {1, 1, 4}, {4, 1, 2}};
+  constexpr int kCand4 = 6;  // the first six are the 4-wave blocks
+  // 8 waves sharing one window: plain convs whose tiles would otherwise be split four ways, four row tiles each staging ≥ 128 rows
   int best = -1;
   static const char* force = getenv("PIPER_HIP_WIN_CFG");  // tuning hook: "WM,WN,KS"
   int fm = 0, fn = 0, fk = 0;
   const bool forced = force && sscanf(force, "%d,%d,%d", &fm, &fn, &fk) == 3;
+  if (!forced && a.ct_stride == 0 && g.MT % 4 == 0 && a.Cin >= 128 && KS == 4 && Sp_min / 2 >= 16 && lds_bytes(a.Cin, 1, reach, 2, 4) <= 160 * 1024) best = 6;
   for (int pass = 0; pass < 3 && best < 0; pass++)  // 0: forced, 1: wanted KS, 2: anything that fits
-    for (int i = 0; i < 6 && best < 0; i++) {
+    for (int i = 0; i < (pass == 0 ? 7 : kCand4) && best < 0; i++) {
       const int m = cand[i][0], nn = cand[i][1], k = cand[i][2];
       if (g.MT % m || (k > 1 && Sp_min / k < 16) || lds_bytes(a.Cin, nn, reach, k, m * nn) > 160 * 1024) continue;
       if (pass == 0 && !(forced && m == fm && nn == fn && k == fk)) continue;
@@ -401,9 +423,14 @@ int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* 
   const dim3 grid((unsigned)ceil_div(a.Lout, WN * 32), (unsigned)ceil_div(g.MT, WM), (unsigned)(a.N * count));
   ConvWinMulti multi;
   for (int i = 0; i < kWinMulti; i++) multi.c[i] = convs[i < count ? i : 0];
+  // row-tile groups pinned to XCDs when the weight image is the larger operand (see the kernel)
+  static const bool no_xcd = getenv("PIPER_HIP_WIN_NO_XCD_ROWS") != nullptr;
+  const int64_t w_bytes = (int64_t)g.MT * Sp_min * 256, x_bytes = (int64_t)a.Cin * a.Lin * 4 * (a.x2 ? 3 : 1);
+  const int xcd_rows = (!no_xcd && grid.y % 8 == 0 && w_bytes > x_bytes) ? 1 : 0;
 #define PH_WIN_CASE(M, N_, K_) \
-  if (WM == M && WN == N_ && KS == K_) launch_inst<M, N_, K_>(s, multi, a.N, grid, lds); else
+  if (WM == M && WN == N_ && KS == K_) launch_inst<M, N_, K_>(s, multi, a.N, grid, lds, xcd_rows); else
   PH_WIN_CASE(4, 1, 1) PH_WIN_CASE(2, 2, 1) PH_WIN_CASE(1, 4, 1) PH_WIN_CASE(2, 1, 2) PH_WIN_CASE(1, 2, 2) PH_WIN_CASE(1, 1, 4)
+  PH_WIN_CASE(4, 1, 2)
   PH_FAIL(PIPER_HIP_ERR_UNSUPPORTED, "conv_win: no instance for WM=%d WN=%d KS=%d", WM, WN, KS);
 #undef PH_WIN_CASE
   hipError_t e = hipGetLastError();
