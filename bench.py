@@ -409,7 +409,7 @@ def main():
     if not args.no_scale_bench and rank == 0:
         import katdata as kd
         rs = np.random.RandomState(20240607)
-        lat, buckets, built = [], set(), 0
+        lat, buckets, built, detail = [], set(), 0, []
         for i in range(200):
             Tn = int(np.clip(np.exp(rs.normal(np.log(90.0), 0.6)), 14, 400))
             rid = [FIXTURE_IDS[j % 14] for j in range(Tn)]
@@ -417,16 +417,24 @@ def main():
             rnz = kd.sym(5000 + i, (cfg.inter, int(sum(rdur))), 1.7320508)
             a = time.perf_counter()
             rt.prepare(2, rid, rdur, rnz, 0.667)
+            b = time.perf_counter()
             rt.launch(2)
+            c = time.perf_counter()
             rt.collect(2)
-            lat.append((time.perf_counter() - a) * 1e3)
+            d = time.perf_counter()
+            lat.append((d - a) * 1e3)
             pi = rt.plan_info(2)
-            buckets.add((pi["bucket_t"], pi["bucket_f"]))
+            bk = (pi["bucket_t"], pi["bucket_f"])
+            detail.append({"ms": round(lat[-1], 3), "request": i, "ids": Tn, "frames": int(sum(rdur)), "bucket": list(bk), "new_bucket": bk not in buckets,
+                           "prepare_launch_collect_ms": [round((b - a) * 1e3, 3), round((c - b) * 1e3, 3), round((d - c) * 1e3, 3)],
+                           "build": rt.last_build_breakdown() if bk not in buckets else None})
+            buckets.add(bk)
         tail = lat[20:]
         out["request_stream"] = {"requests": len(lat), "distinct_buckets": len(buckets), "cached_plans": rt.plan_info(2)["cached_plans"],
                                  "ms_p50": round(percentile(lat, 50), 3), "ms_p95": round(percentile(lat, 95), 3), "ms_max": round(max(lat), 3),
                                  "ms_p50_after_20": round(percentile(tail, 50), 3), "ms_p95_after_20": round(percentile(tail, 95), 3),
                                  "ms_max_after_20": round(max(tail), 3), "ms_first": round(lat[0], 3),
+                                 "slowest": sorted(detail, key=lambda d: -d["ms"])[:3],
                                  "note": "ids-to-audio per request incl. H2D of ids / durations / noise and D2H of the waveform; log-normal lengths (median 90 ids), seeded"}
     if bcast_ms is not None:
         import torch.distributed as dist

@@ -68,6 +68,11 @@ void piper_hip_destroy(piper_hip_ctx* ctx);
  * returns the cached free blocks to the driver (the role ARC plays for MTLBuffer in the reference). */
 int piper_hip_memory_stats(piper_hip_ctx* ctx, size_t* reserved_bytes, size_t* live_bytes);
 int piper_hip_memory_trim(piper_hip_ctx* ctx);
+/* Take `bytes` of device memory from the driver NOW, in one piece, and serve later allocations of this context (plan arenas, op outputs) from
+ * it before asking the driver again. A fresh driver allocation is cheap to make but its first use can stall the GPU for tens of milliseconds
+ * (page mapping / clearing): a serving process pays that while it loads. One slab per context (later calls are no-ops); piper_hip_voice_create
+ * reserves 8 GiB (of the 288 GB of an MI355X; halved until it fits on a smaller part) if nothing was reserved before it (the reference's heaps: MetalBackend.swift:34-39 allocates per buffer). */
+int piper_hip_memory_reserve(piper_hip_ctx* ctx, size_t bytes);
 /* MetalBackend.allocateBuffer(length:) (MetalBackend.swift:34-39): at least 1 byte is allocated. */
 int piper_hip_alloc(piper_hip_ctx* ctx, size_t bytes, void** out);
 /* Buffer release (ARC drop in the reference; GraphExecutor.swift:216-225). Returns memory to the

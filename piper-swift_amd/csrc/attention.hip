@@ -1060,3 +1060,4 @@ PH_EXPORT int piper_hip_attention_block_f32(piper_hip_ctx* ctx, const float* q, 
   if (rc) return rc;
   return ss.finish("attention_block_f32");
 }
+namespace { PH_WARM(attention, (rel_attention_lds_kernel<96, false>)); }

@@ -69,6 +69,14 @@ struct Pool {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_cache;
   size_t bytes_reserved = 0;
+  // One slab taken from the driver up front (reserve): blocks the free lists cannot serve are carved from it before hipMalloc is asked.
+  // A fresh hipMalloc is cheap on the host but its first use can stall the GPU for tens of milliseconds while the driver maps and clears
+  // the pages (r3, tools/probe/request_max.py: 27 ms in the first synchronisation after a plan build, on requests worth 1 ms) — a voice
+  // reserves its plan memory while it loads instead (piper_hip_memory_reserve; voice_create does it once per context).
+  char* slab = nullptr;
+  size_t slab_size = 0, slab_off = 0;
+  bool in_slab(const void* p) const { return slab && (const char*)p >= slab && (const char*)p < slab + slab_size; }
+  int reserve(size_t bytes);
   int alloc(size_t bytes, void** out);
   int release(void* p);  // immediate reuse: only for blocks whose users are known to be complete
   // stream-ordered release: reusable once everything enqueued so far on `streams` has run
@@ -76,6 +84,18 @@ struct Pool {
   void reap(bool wait);  // move completed pending blocks to the free list (wait = block until all are complete)
   void trim();
 };
+
+// Code objects are loaded lazily, one per translation unit, when its first kernel is launched — 1 … 13 ms that land on whichever request
+// first needs a kernel of a unit nothing touched before (r3, tools/probe/request_max.py: the first long request of a process took 14 ms
+// instead of 2 because it was the first to leave the short-row kernels). Every unit registers one of its kernels here; voice_create asks
+// the runtime for that kernel's attributes (warm_all_modules), which loads the unit while the voice loads.
+struct WarmReg { explicit WarmReg(void (*f)()); };
+void warm_all_modules();
+#define PH_WARM(tag, kernel)                                                                              \
+  static const ::ph::WarmReg warm_reg_##tag([] {                                                          \
+    hipFuncAttributes at_;                                                                                \
+    if (hipFuncGetAttributes(&at_, (const void*)(kernel)) != hipSuccess) (void)hipGetLastError();        \
+  })
 
 // per-device "already opted in to > 64 KiB of dynamic LDS" flags (hipFuncSetAttribute is per device)
 constexpr int kMaxDevices = 64;

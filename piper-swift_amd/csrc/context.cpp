@@ -1,5 +1,6 @@
 // context.cpp — device context, pooled buffers, transfers, streams, timers.
 // Replaces Metal/MetalContext.swift:4-62 and the buffer/blit helpers of MetalBackend.swift:34-66, 841-874, 963-993.
+#include <mutex>
 #include "common.h"
 
 namespace ph {
@@ -32,6 +33,16 @@ const char* tuning_getenv(const char* name) {
   return v;
 }
 #define getenv(name) ::ph::tuning_getenv(name)
+
+static std::vector<void (*)()>& warm_list() {
+  static std::vector<void (*)()> v;
+  return v;
+}
+WarmReg::WarmReg(void (*f)()) { warm_list().push_back(f); }
+void warm_all_modules() {
+  static std::once_flag once;
+  std::call_once(once, [] { for (auto f : warm_list()) f(); });
+}
 
 static size_t bucket_of(size_t bytes) {
   size_t b = 256;
@@ -96,16 +107,26 @@ int Pool::alloc(size_t bytes, void** out) {
     live[*out] = b;
     return PIPER_HIP_OK;
   }
+  if (slab && slab_off + b <= slab_size) {  // carve (b is a power of two ≥ 256: the offset stays 256-byte aligned)
+    *out = slab + slab_off;
+    slab_off += b;
+    live[*out] = b;
+    return PIPER_HIP_OK;
+  }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, b);
   if (e != hipSuccess) {
-    // give cached blocks back to the driver and retry once
+    // give cached blocks back to the driver and retry once (blocks carved from the slab stay on their lists)
     (void)hipGetLastError();
     reap(true);
     for (auto& kv : free_blocks) {
-      for (void* q : kv.second) (void)hipFree(q);
-      bytes_reserved -= kv.first * kv.second.size();
-      kv.second.clear();
+      std::vector<void*> keep;
+      for (void* q : kv.second) {
+        if (in_slab(q)) { keep.push_back(q); continue; }
+        (void)hipFree(q);
+        bytes_reserved -= kv.first;
+      }
+      kv.second.swap(keep);
     }
     e = hipMalloc(&p, b);
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_ALLOC, "hipMalloc(%zu) failed: %s", b, hipGetErrorString(e));
@@ -113,6 +134,27 @@ int Pool::alloc(size_t bytes, void** out) {
   bytes_reserved += b;
   live[p] = b;
   *out = p;
+  return PIPER_HIP_OK;
+}
+
+int Pool::reserve(size_t bytes) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (slab || bytes == 0) return PIPER_HIP_OK;  // one slab per context; a second call is a no-op
+  void* p = nullptr;
+  size_t want = (bytes + 255) & ~(size_t)255;
+  hipError_t e = hipMalloc(&p, want);
+  while (e != hipSuccess && want > ((size_t)64 << 20)) {  // a smaller card: halve until it fits
+    (void)hipGetLastError();
+    want >>= 1;
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); return PIPER_HIP_OK; }  // not fatal: allocations fall through to hipMalloc
+  // touch it now: the driver maps (and clears) the pages here, not under the first request that lands on them
+  if (hipMemset(p, 0, want) != hipSuccess || hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+  slab = (char*)p;
+  slab_size = want;
+  slab_off = 0;
+  bytes_reserved += want;
   return PIPER_HIP_OK;
 }
 
@@ -131,10 +173,15 @@ void Pool::trim() {
   for (hipEvent_t e : event_cache) (void)hipEventDestroy(e);
   event_cache.clear();
   for (auto& kv : free_blocks)
-    for (void* q : kv.second) (void)hipFree(q);
+    for (void* q : kv.second)
+      if (!in_slab(q)) (void)hipFree(q);
   free_blocks.clear();
-  for (auto& kv : live) (void)hipFree(kv.first);
+  for (auto& kv : live)
+    if (!in_slab(kv.first)) (void)hipFree(kv.first);
   live.clear();
+  if (slab) (void)hipFree(slab);
+  slab = nullptr;
+  slab_size = slab_off = 0;
   bytes_reserved = 0;
 }
 
@@ -376,6 +423,12 @@ PH_EXPORT int piper_hip_memory_stats(piper_hip_ctx* ctx, size_t* reserved_bytes,
   return PIPER_HIP_OK;
 }
 
+PH_EXPORT int piper_hip_memory_reserve(piper_hip_ctx* ctx, size_t bytes) {
+  PH_CHECK_CTX(ctx);
+  PH_HIP(hipSetDevice(ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
+  return ctx->pool.reserve(bytes);
+}
+
 PH_EXPORT int piper_hip_memory_trim(piper_hip_ctx* ctx) {
   PH_CHECK_CTX(ctx);
   PH_HIP(hipSetDevice(ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
@@ -383,10 +436,14 @@ PH_EXPORT int piper_hip_memory_trim(piper_hip_ctx* ctx) {
   ph::release_deferred(ctx);
   std::lock_guard<std::mutex> lk(ctx->pool.mu);
   ctx->pool.reap(true);
-  for (auto& kv : ctx->pool.free_blocks) {
-    for (void* q : kv.second) (void)hipFree(q);
-    ctx->pool.bytes_reserved -= kv.first * kv.second.size();
-    kv.second.clear();
+  for (auto& kv : ctx->pool.free_blocks) {  // blocks carved from the reserved slab stay cached: the slab is one allocation
+    std::vector<void*> keep;
+    for (void* q : kv.second) {
+      if (ctx->pool.in_slab(q)) { keep.push_back(q); continue; }
+      (void)hipFree(q);
+      ctx->pool.bytes_reserved -= kv.first;
+    }
+    kv.second.swap(keep);
   }
   return PIPER_HIP_OK;
 }

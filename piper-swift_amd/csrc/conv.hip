@@ -710,3 +710,4 @@ int launch_convt_direct(piper_hip_ctx* ctx, hipStream_t s, const float* x, const
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv, pack_conv_kernel); } }

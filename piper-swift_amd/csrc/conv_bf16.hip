@@ -437,3 +437,4 @@ int launch_conv_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvBf16Args
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_bf16, pack_conv_bf16_kernel); } }

@@ -8,3 +8,4 @@ template bool launch_k<11, 16>(hipStream_t, const ConvArgs&, int, int, int, int,
 template bool launch_tile_k<11>(hipStream_t, const ConvArgs&, int, int, int);
 }  // namespace detail
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_inst_k11, (detail::conv_stream_kernel<11, 1, false, 0, 256, 16>)); } }

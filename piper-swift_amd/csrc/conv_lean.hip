@@ -601,3 +601,4 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_lean, (conv_k1_kernel<6, 0>)); } }

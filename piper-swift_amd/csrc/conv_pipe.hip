@@ -541,3 +541,4 @@ int launch_conv_pipe_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs*
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_pipe, pack_pipe_kernel); } }

@@ -443,3 +443,4 @@ int try_launch_conv_short(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& a_i
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_short, (conv_short_kernel<7, 1, 0, false, 512>)); } }

@@ -439,3 +439,4 @@ int launch_conv_win_multi(piper_hip_ctx* ctx, hipStream_t s, const ConvWinArgs* 
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(conv_win, pack_conv_win_kernel); } }

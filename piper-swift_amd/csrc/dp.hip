@@ -468,3 +468,4 @@ int launch_dp_final(hipStream_t s, const float* z, const float* m, const float* 
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(dp, dp_init_kernel); } }

@@ -110,3 +110,4 @@ int launch_flow_seam(hipStream_t s, const float* skip, float* zp, float* h, cons
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(flow_seam, flow_seam_kernel); } }

@@ -807,3 +807,4 @@ PH_EXPORT int piper_hip_matmul_f32(piper_hip_ctx* ctx, const float* a, const int
   }
   return ss.finish("matmul_f32");
 }
+namespace { PH_WARM(ops_basic, gather4_kernel); }

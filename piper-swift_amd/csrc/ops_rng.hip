@@ -49,3 +49,4 @@ PH_EXPORT int piper_hip_random_draws_u32(piper_hip_ctx* ctx, size_t count, uint6
   hipLaunchKernelGGL(random_draws_kernel, dim3(grid), dim3(kBlock), 0, ss.s, *out, count, (unsigned)(seed & 0xffffffffu));
   return ss.finish("random_draws_u32");
 }
+namespace { PH_WARM(ops_rng, random_normal_like_kernel); }

@@ -436,3 +436,4 @@ int launch_rb_pair_multi(piper_hip_ctx* ctx, hipStream_t s, const RbPairArgs* pa
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(rb_pair, (rb_pair_kernel<1>)); } }

@@ -323,3 +323,4 @@ int launch_rb_pair_bf16_multi(piper_hip_ctx* ctx, hipStream_t s, const RbPairBf1
 }
 
 }  // namespace ph
+namespace ph { namespace { PH_WARM(rb_pair_bf16, (rb_pair_bf16_kernel<1, 1>)); } }

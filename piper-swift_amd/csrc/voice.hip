@@ -145,10 +145,35 @@ __global__ __launch_bounds__(kBlock) void flip_channels_kernel(const float* __re
 // keeps the GPU busy for `ticks` of the 100 MHz realtime counter: lets the host queue a whole profiled pass ahead of the
 // GPU, so the per-launch event deltas contain the ~1.7 µs kernel boundary but not host launch latency
 __global__ void empty_kernel() {}
+// lensT / lensF of a fresh plan = the bucket's own lengths (a kernel, not a copy from a host vector: see stream_wait below — nothing on the
+// request path hands PAGEABLE host memory to an asynchronous copy)
+__global__ void fill_lens_kernel(int* __restrict__ lensT, int* __restrict__ lensF, int T, int F, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { lensT[i] = T; lensF[i] = F; }
+}
 
 __global__ void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+// Wait for a stream on the request path. hipStreamSynchronize parks the thread on an interrupt; on the GPU boxes of this pool a wake-up is
+// now and then 25 … 35 ms late (r3, tools/probe/request_max.py: the same ~26 ms in whichever synchronisation of a request it hits — arena
+// initialisation, prepare, collect — on requests whose GPU work is 1 ms). A request is short: poll the stream for up to 5 ms, then park.
+hipError_t stream_wait(hipStream_t q) {
+  static const bool park = getenv("PIPER_HIP_NO_SPIN_WAIT") != nullptr;
+  if (!park) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(q);
+      if (e != hipErrorNotReady) return e;
+      (void)hipGetLastError();  // "not ready" must not show up as the sticky error of a later launch check
+      if (clk::now() - t0 > std::chrono::milliseconds(5)) break;
+      for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize(q);
 }
 
 struct Step {
@@ -309,6 +334,9 @@ struct piper_hip_voice {
     // back (frames per item, durations) — the last two written by a kernel through the host mapping
     char* h_misc = nullptr; float* h_dpn = nullptr; int32_t* h_res = nullptr;
     size_t cap_misc = 0, cap_dpn = 0, cap_res = 0;
+    float* h_noise = nullptr;  // the caller's noise tensors, laid out in bucket rows (prepare_batch)
+    size_t cap_noise = 0;
+    std::vector<hipEvent_t> chunk_ev;  // collect, 1 … 16 MB waveforms: one event per 1 MB chunk landed in h_audio
   } staging[kMaxSlots];
   Slot* attached[kMaxSlots] = {};
   Slot* attached_dp[kMaxSlots] = {};  // bounded prepare: the encoder + predictor plan this slot id holds until its next prepare / detach
@@ -1673,6 +1701,20 @@ int run_schedule(Slot& s, hipStream_t q, bool parallel) {
   return PIPER_HIP_OK;
 }
 
+// The first device → host copy a STREAM hands to the copy engine costs 7 … 17 ms (r3, tools/probe/first_run.py with PIPER_HIP_COLLECT_DMA=1:
+// 8.1 ms in collect for 1.0 ms of GPU work; warming another stream of the process did not help). Every stream a plan will use gets that copy
+// out of the way when it is created — while the voice loads for the four it pre-creates.
+void warm_stream_copies(piper_hip_voice* v, hipStream_t q) {
+  void* hp = nullptr;
+  const size_t nb = std::min<size_t>((size_t)2 << 20, v->blob_floats * sizeof(float));  // large enough for the copy ENGINE (small ones are blitted)
+  if (!v->blob || hipHostMalloc(&hp, nb) != hipSuccess) { (void)hipGetLastError(); return; }
+  hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, q);  // as in a request: the copy waits for a kernel of the same stream
+  (void)hipMemcpyAsync(hp, v->blob, nb, hipMemcpyDeviceToHost, q);
+  (void)hipStreamSynchronize(q);
+  (void)hipHostFree(hp);
+  (void)hipGetLastError();
+}
+
 int slot_init(piper_hip_voice* v, Slot& s) {
   if (s.inited) return PIPER_HIP_OK;
   if (!v->free_sets.empty()) {  // a set an evicted plan left behind
@@ -1688,6 +1730,7 @@ int slot_init(piper_hip_voice* v, Slot& s) {
   PH_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev0), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipEventCreate(&s.ev1), PIPER_HIP_ERR_LAUNCH);
+  warm_stream_copies(v, s.stream);
   s.inited = true;
   return PIPER_HIP_OK;
 }
@@ -1778,6 +1821,43 @@ PH_EXPORT int piper_hip_voice_create(piper_hip_ctx* ctx, const piper_hip_voice_c
     fail(0);
     PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_create: packing failed: %s", hipGetErrorString(e));
   }
+  ph::warm_all_modules();  // every translation unit's code object, now instead of under the first request that needs it (common.h)
+  // plan memory up front (Pool::reserve): a no-op when the host reserved its own amount before creating the voice
+  {
+    static const size_t reserve_mb = [] { const char* e = getenv("PIPER_HIP_RESERVE_MB"); return e ? (size_t)atoll(e) : (size_t)8192; }();
+    (void)ctx->pool.reserve(reserve_mb << 20);
+  }
+  // Four stream sets up front: creating a HIP stream costs ≈ 3 ms (8 ms for the first of a process, tools/probe/cold_prepare.py) — paid here,
+  // while the voice loads, it is off the first request (first_request_ms 21 → 13 in bench.py). Plans take sets from this list (slot_init)
+  // and give them back when they go idle (detach); a voice serving more than four slot ids at once creates the rest on demand.
+  for (int i = 0; i < 4; i++) {
+    piper_hip_voice::StreamSet st = {};
+    if (hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&st.ev0) != hipSuccess || hipEventCreate(&st.ev1) != hipSuccess) {
+      (void)hipGetLastError();
+      if (st.ev0) (void)hipEventDestroy(st.ev0);
+      if (st.stream) (void)hipStreamDestroy(st.stream);
+      break;  // not fatal: slot_init creates what is missing
+    }
+    v->free_sets.push_back(st);
+  }
+  // … and the process's first graph capture + instantiate (≈ 8 ms against ≈ 1 ms for later ones: the runtime sets its graph machinery up
+  // on first use) on a one-kernel graph, for the same reason. Failure is not fatal.
+  if (!v->free_sets.empty()) {
+    const hipStream_t q = v->free_sets[0].stream;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipStreamBeginCapture(q, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, q);
+      if (hipStreamEndCapture(q, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge) {
+        (void)hipGraphLaunch(ge, q);
+        (void)hipStreamSynchronize(q);
+      }
+    }
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+  }
+  for (auto& st : v->free_sets) warm_stream_copies(v.get(), st.stream);
   *out = v.release();
   return PIPER_HIP_OK;
 }
@@ -1881,6 +1961,8 @@ PH_EXPORT void piper_hip_voice_destroy(piper_hip_voice* v) {
     if (sg.h_misc) (void)hipHostFree(sg.h_misc);
     if (sg.h_dpn) (void)hipHostFree(sg.h_dpn);
     if (sg.h_res) (void)hipHostFree(sg.h_res);
+    if (sg.h_noise) (void)hipHostFree(sg.h_noise);
+    for (hipEvent_t e : sg.chunk_ev) (void)hipEventDestroy(e);
   }
   for (auto& st : v->free_sets) {
     for (hipEvent_t e : {st.ev0, st.ev1, st.ev_fork, st.ev_join[0], st.ev_join[1]})
@@ -1990,16 +2072,14 @@ int acquire_plan(piper_hip_voice* v, int kind, int Tb, int Fb, int NB, Slot** ou
   Slot& s = *np;
   // a plan may be captured / profiled before every input has been uploaded: give the length arrays and index inputs legal values
   {
-    std::vector<int> full((size_t)2 * NB);
-    for (int b = 0; b < NB; b++) { full[b] = Tb; full[NB + b] = Fb; }
-    hipError_t e = hipMemcpyAsync(s.lensT, full.data(), NB * sizeof(int), hipMemcpyHostToDevice, s.stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(s.lensF, full.data() + NB, NB * sizeof(int), hipMemcpyHostToDevice, s.stream);
+    hipLaunchKernelGGL(fill_lens_kernel, dim3((unsigned)ceil_div(NB, 64)), dim3(64), 0, s.stream, s.lensT, s.lensF, Tb, Fb, NB);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess && s.ids) e = hipMemsetAsync(s.ids, 0, (size_t)NB * Tb * sizeof(int64_t), s.stream);
     if (e == hipSuccess && s.frame2id) e = hipMemsetAsync(s.frame2id, 0, (size_t)NB * Fb * sizeof(int32_t), s.stream);
     if (e == hipSuccess && s.rng) e = hipMemsetAsync(s.rng, 0, (size_t)NB * 2 * sizeof(unsigned), s.stream);
     if (e == hipSuccess && s.dp_scalars) e = hipMemsetAsync(s.dp_scalars, 0, dp_scalars_bytes(NB), s.stream);
     if (e == hipSuccess && s.dp_noise) e = hipMemsetAsync(s.dp_noise, 0, (size_t)NB * 2 * Tb * sizeof(float), s.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);  // `full` is a local
+    if (e == hipSuccess) e = stream_wait(s.stream);
     if (e != hipSuccess) { slot_release(v, s, true); PH_FAIL(PIPER_HIP_ERR_LAUNCH, "voice_prepare: arena initialisation failed: %s", hipGetErrorString(e)); }
   }
   lap();
@@ -2040,6 +2120,17 @@ void detach(piper_hip_voice* v, int slot) {
 
 namespace {
 int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int32_t* durations_out, float* logw_out, int max_entries, Slot** plan_out);
+template <typename Tp>
+int grow_pinned(Tp*& p, size_t& cap, size_t need) {
+  if (cap >= need) return PIPER_HIP_OK;
+  if (p) (void)hipHostFree(p);
+  p = nullptr; cap = 0;
+  size_t c = 1024;
+  while (c < need) c <<= 1;
+  PH_HIP(hipHostMalloc((void**)&p, c * sizeof(Tp)), PIPER_HIP_ERR_ALLOC);
+  cap = c;
+  return PIPER_HIP_OK;
+}
 }
 
 PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int slot) {
@@ -2114,7 +2205,7 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   Slot& s = *cur;
   s.last_use = ++v->use_clock;
   // the previous launch on this plan may still be reading the inputs
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
   s.bounded_pending = false;
   if (v->attached_dp[slot]) { v->attached_dp[slot]->in_use = false; v->attached_dp[slot] = nullptr; }
   if (kind == 3)  // the predictor's plan has finished (predict synchronises): its projection becomes this plan's input
@@ -2158,6 +2249,17 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
   s.h_noise_scale.resize(n);
   s.h_rng.resize(2 * (size_t)n);
   s.h_dur.clear();
+  // Everything that goes to the device leaves from page-locked memory of the slot id: an asynchronous copy from PAGEABLE memory makes the
+  // runtime pin (or stage) the caller's pages on the spot. The noise tensor is copied into bucket rows here, on the host.
+  auto& sgp = v->staging[slot];
+  {
+    size_t noise_floats = 0;
+    for (int b = 0; b < n; b++) if (utts[b].noise) noise_floats = (size_t)n * I * F;
+    if (noise_floats && (rc = grow_pinned(sgp.h_noise, sgp.cap_noise, noise_floats))) return rc;
+    if ((rc = grow_pinned(sgp.h_misc, sgp.cap_misc, (size_t)n * (2 * sizeof(unsigned) + sizeof(float)) + 64))) return rc;
+  }
+  unsigned* p_rng = (unsigned*)sgp.h_misc;
+  float* p_ns = (float*)(p_rng + 2 * (size_t)n);
   for (int b = 0; b < n; b++) {
     const piper_hip_utterance* u = &utts[b];
     const int Tb = hT[b], Fb = hF[b];
@@ -2174,19 +2276,25 @@ PH_EXPORT int piper_hip_voice_prepare_batch(piper_hip_voice* v, const piper_hip_
     for (; f < F; f++) s.h_f2i[(size_t)b * F + f] = 0;
     s.h_noise_scale[b] = u->noise_scale;
     // noise [I, Fb] → rows of the bucket [I, F]
-    if (u->noise)
-      PH_HIP(hipMemcpy2DAsync(s.noise + (size_t)b * I * F, (size_t)F * sizeof(float), u->noise, (size_t)Fb * sizeof(float), (size_t)Fb * sizeof(float),
-                              (size_t)I, hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-    else if (!s.h_rng[2 * b])
+    p_rng[2 * b] = s.h_rng[2 * b]; p_rng[2 * b + 1] = s.h_rng[2 * b + 1];
+    p_ns[b] = u->noise_scale;
+    if (u->noise) {
+      float* hb = sgp.h_noise + (size_t)b * I * F;
+      for (int c = 0; c < I; c++) {
+        memcpy(hb + (size_t)c * F, u->noise + (size_t)c * Fb, (size_t)Fb * sizeof(float));
+        if (Fb < F) memset(hb + (size_t)c * F + Fb, 0, (size_t)(F - Fb) * sizeof(float));
+      }
+      PH_HIP(hipMemcpyAsync(s.noise + (size_t)b * I * F, hb, (size_t)I * F * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+    } else if (!s.h_rng[2 * b])
       PH_HIP(hipMemsetAsync(s.noise + (size_t)b * I * F, 0, (size_t)I * F * sizeof(float), s.stream), PIPER_HIP_ERR_LAUNCH);
   }
-  PH_HIP(hipMemcpyAsync(s.rng, s.h_rng.data(), 2 * (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipMemcpyAsync(s.noise_scale, s.h_noise_scale.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.rng, p_rng, 2 * (size_t)n * sizeof(unsigned), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(hipMemcpyAsync(s.noise_scale, p_ns, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.ids, s.h_ids, (size_t)T * n * sizeof(int64_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.frame2id, s.h_f2i, (size_t)F * n * sizeof(int32_t), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.lensT, s.h_lens, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipMemcpyAsync(s.lensF, s.h_lens + n, (size_t)n * sizeof(int), hipMemcpyHostToDevice, s.stream), PIPER_HIP_ERR_LAUNCH);
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // noise / scalars come from caller memory
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);  // noise / scalars come from caller memory
   s.timed = false;
   return slot;
 }
@@ -2245,17 +2353,6 @@ __global__ __launch_bounds__(256) void dp_paths_kernel(const int32_t* __restrict
   }
 }
 
-template <typename Tp>
-int grow_pinned(Tp*& p, size_t& cap, size_t need) {
-  if (cap >= need) return PIPER_HIP_OK;
-  if (p) (void)hipHostFree(p);
-  p = nullptr; cap = 0;
-  size_t c = 1024;
-  while (c < need) c <<= 1;
-  PH_HIP(hipHostMalloc((void**)&p, c * sizeof(Tp)), PIPER_HIP_ERR_ALLOC);
-  cap = c;
-  return PIPER_HIP_OK;
-}
 }  // namespace
 
 // Whole utterances with PREDICTED durations and no host round trip between the predictor and the rest: the caller states an upper bound on
@@ -2294,7 +2391,7 @@ PH_EXPORT int piper_hip_voice_prepare_batch_bounded(piper_hip_voice* v, const pi
   }
   Slot& s = *cur;
   s.last_use = ++v->use_clock;
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);  // the previous request of this slot id: its staging and its predictor plan are idle now
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);  // the previous request of this slot id: its staging and its predictor plan are idle now
   Slot* dp = v->attached_dp[slot];
   if (dp && !(dp->built && dp->T == T && dp->NB == n && dp->prec == v->precision)) { dp->in_use = false; dp = v->attached_dp[slot] = nullptr; }
   if (!dp) {
@@ -2450,7 +2547,7 @@ int predict_impl(piper_hip_voice* v, const piper_hip_utterance* utts, int n, int
   std::vector<float> lw(logw_out ? (size_t)n * T : 0);
   if (e == hipSuccess) e = hipMemcpyAsync(dur.data(), s.dp_dur, dur.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s.stream);
   if (e == hipSuccess && logw_out) e = hipMemcpyAsync(lw.data(), s.taps["logw"].p, lw.size() * sizeof(float), hipMemcpyDeviceToHost, s.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+  if (e == hipSuccess) e = stream_wait(s.stream);
   if (plan_out && e == hipSuccess) *plan_out = pl;  // stays in_use: see above
   else s.in_use = false;
   evict_idle_plans(v);
@@ -2591,7 +2688,7 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
         PH_HIP(hipGetLastError(), PIPER_HIP_ERR_LAUNCH);
       }
     }
-    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
     const int frc = bounded_finish(v, slot, s);
     if (frc) return frc;
     if (dst_dev) {
@@ -2614,6 +2711,11 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     // the plan by one DMA and is copied out by the host; beyond that the runtime's pipelined chunks beat DMA + memcpy
     // (factor 64, 2.75 MB: +0.12 ms with the pinned hop).
     constexpr size_t kPinnedMax = (size_t)1 << 20;
+    // 1 … 16 MB into PAGEABLE memory: handing the caller's buffer to the runtime makes it page-lock that buffer on the spot, and for a buffer
+    // it has not seen before that took 7 ms (r3, tools/probe/first_run.py: the first 1.2 MB waveform of a process, 9.4 ms in collect for
+    // 1.9 ms of GPU work). Such waveforms land in the slot id's page-locked buffer in 1 MB chunks, each followed by an event, and the host
+    // copies chunk k out while chunk k + 1 is on the wire. Larger ones still go to the runtime (its pipelined staging wins there).
+    constexpr size_t kChunkedMax = (size_t)16 << 20, kChunk = (size_t)1 << 20;
     const size_t bytes = (size_t)total * sizeof(float);
     // a destination the caller page-locked itself (piper_hip_host_alloc) takes the DMA directly
     bool caller_pinned = false;
@@ -2624,7 +2726,7 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
     }
     {
       auto& sg = v->staging[slot];
-      if (!caller_pinned && bytes <= kPinnedMax && sg.audio_cap < bytes) {
+      if (!caller_pinned && bytes <= kChunkedMax && sg.audio_cap < bytes) {
         if (sg.h_audio) (void)hipHostFree(sg.h_audio);
         sg.h_audio = nullptr; sg.audio_cap = 0;
         size_t c = 65536;
@@ -2633,6 +2735,42 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
         else { sg.h_audio = nullptr; (void)hipGetLastError(); }
       }
       s.h_audio = sg.audio_cap >= bytes ? sg.h_audio : nullptr;
+    }
+    if (!caller_pinned && bytes > kPinnedMax && bytes <= kChunkedMax && s.h_audio) {
+      auto& sg = v->staging[slot];
+      // the items back to back in the staging buffer, cut into chunks; `cuts` = end offset (floats) of each chunk
+      std::vector<int64_t> cuts;
+      int64_t off = 0;
+      for (int b = 0; b < s.NB; b++) {
+        const int64_t nb = (int64_t)s.h_F[b] * v->hop;
+        const float* src = s.audio + (int64_t)b * s.n_samples;
+        for (int64_t c0 = 0; c0 < nb; c0 += (int64_t)(kChunk / sizeof(float))) {
+          const int64_t cn = std::min<int64_t>((int64_t)(kChunk / sizeof(float)), nb - c0);
+          PH_HIP(hipMemcpyAsync(s.h_audio + off + c0, src + c0, (size_t)cn * sizeof(float), hipMemcpyDeviceToHost, s.stream), PIPER_HIP_ERR_LAUNCH);
+          const size_t k = cuts.size();
+          if (sg.chunk_ev.size() <= k) {
+            hipEvent_t e = nullptr;
+            PH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming), PIPER_HIP_ERR_LAUNCH);
+            sg.chunk_ev.push_back(e);
+          }
+          PH_HIP(hipEventRecord(sg.chunk_ev[k], s.stream), PIPER_HIP_ERR_LAUNCH);
+          cuts.push_back(off + c0 + cn);
+        }
+        off += nb;
+      }
+      int64_t done = 0;
+      for (size_t k = 0; k < cuts.size(); k++) {
+        for (;;) {  // poll: the chunks arrive every ≈ 20 µs
+          const hipError_t e = hipEventQuery(sg.chunk_ev[k]);
+          if (e == hipSuccess) break;
+          if (e != hipErrorNotReady) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "collect: %s", hipGetErrorString(e));
+          (void)hipGetLastError();
+          for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+        }
+        memcpy(host_audio + done, s.h_audio + done, (size_t)(cuts[k] - done) * sizeof(float));
+        done = cuts[k];
+      }
+      return PIPER_HIP_OK;
     }
     float* dst = (!caller_pinned && bytes <= kPinnedMax && s.h_audio) ? s.h_audio : host_audio;
     // Short waveforms into page-locked memory are written by a KERNEL through the host mapping instead of the copy engine: the
@@ -2656,11 +2794,11 @@ PH_EXPORT int piper_hip_voice_collect(piper_hip_voice* v, int slot, float* host_
       }
       off += nb;
     }
-    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
     if (dst != host_audio) memcpy(host_audio, dst, bytes);
     return PIPER_HIP_OK;
   }
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
   return PIPER_HIP_OK;
 }
 
@@ -2693,7 +2831,7 @@ int capture_steps(Slot& s, const std::vector<int>& pick, hipGraph_t* g, hipGraph
     int rc = s.steps[i].run(s.stream);
     if (rc) return rc;
   }
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
   PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);
   int rc = PIPER_HIP_OK;
   for (int i : pick)
@@ -2805,7 +2943,7 @@ PH_EXPORT int piper_hip_voice_tap(piper_hip_voice* v, int slot, const char* name
   if (host) {
     if (max_floats < total) PH_FAIL(PIPER_HIP_ERR_SHAPE, "tap buffer too small");
     PH_HIP(hipSetDevice(v->ctx->device), PIPER_HIP_ERR_UNAVAILABLE);
-    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
     size_t off = 0;
     for (int b = 0; b < s.NB; b++) {
       const size_t len = (size_t)(t.unit == 0 ? s.h_T[b] : s.h_F[b]);
@@ -2857,7 +2995,7 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
       if (!rc && hipEventRecord(ev[i + 1], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
     }
     if (rc) break;
-    PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+    PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
     if (it == 0) continue;
     for (int i = 0; i < n; i++) {
       float ms = 0;
@@ -2876,7 +3014,7 @@ PH_EXPORT int piper_hip_voice_profile(piper_hip_voice* v, int slot, int iters, p
       hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s.stream);
       if (hipEventRecord(ev[i], s.stream) != hipSuccess) rc = PIPER_HIP_ERR_LAUNCH;
     }
-    if (!rc && nf > 0 && hipStreamSynchronize(s.stream) == hipSuccess) {
+    if (!rc && nf > 0 && stream_wait(s.stream) == hipSuccess) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, ev[0], ev[nf]) == hipSuccess) floor_us = ms * 1000.0 / nf;
     }
@@ -2940,7 +3078,7 @@ PH_EXPORT int piper_hip_voice_time_subset(piper_hip_voice* v, int slot, const ch
     if (avg_launch_us) *avg_launch_us = 0;
     return PIPER_HIP_OK;
   }
-  PH_HIP(hipStreamSynchronize(s.stream), PIPER_HIP_ERR_LAUNCH);
+  PH_HIP(stream_wait(s.stream), PIPER_HIP_ERR_LAUNCH);
   hipGraph_t g = nullptr;
   hipGraphExec_t ge = nullptr;
   PH_HIP(hipStreamBeginCapture(s.stream, hipStreamCaptureModeThreadLocal), PIPER_HIP_ERR_LAUNCH);

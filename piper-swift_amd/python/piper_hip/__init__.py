@@ -197,6 +197,7 @@ _PROTOS = {
     "piper_hip_voice_stream_next": (C.c_int, [c_vp, C.c_int, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     "piper_hip_memory_stats": (C.c_int, [c_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "piper_hip_memory_trim": (C.c_int, [c_vp]),
+    "piper_hip_memory_reserve": (C.c_int, [c_vp, C.c_size_t]),
     "piper_hip_voice_set_precision": (C.c_int, [c_vp, C.c_int]),
     "piper_hip_voice_precision": (C.c_int, [c_vp]),
     "piper_hip_voice_destroy": (None, [c_vp]),
@@ -341,6 +342,10 @@ class HipBackend:
         r, l = C.c_size_t(), C.c_size_t()
         _check(self.lib.piper_hip_memory_stats(self.ctx, C.byref(r), C.byref(l)))
         return dict(reserved=r.value, live=l.value)
+
+    def memory_reserve(self, nbytes):
+        """One slab of device memory up front; later allocations are carved from it (no first-touch stalls under requests)."""
+        _check(self.lib.piper_hip_memory_reserve(self.ctx, int(nbytes)))
 
     def memory_trim(self):
         _check(self.lib.piper_hip_memory_trim(self.ctx))
