@@ -533,7 +533,7 @@ def main():
                     n = sum(f["launches"] for f in fam)
                     return (sum(f["launches"] * f["hbm_mb_per_launch"] for f in fam) / n * 1e6 if n else None), pj.get("commit")
                 if args.factor == 8 and args.quality == "medium" and not bf16:
-                    traffic, traffic_commit = per_launch(PROFILE_F32, ("conv_k1_kernel", "conv_gate_kernel", "conv_short_kernel", "conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel", "rb_pair_kernel"))
+                    traffic, traffic_commit = per_launch(PROFILE_F32, ("conv_k1_ln_kernel", "conv_k3_ln_kernel", "conv_k3_r8_kernel", "conv_k1_kernel", "conv_gate_kernel", "conv_short_kernel", "conv_stream_kernel", "conv_win_kernel", "conv_pipe_kernel", "rb_pair_kernel"))
                 elif args.factor == 8 and args.quality == "high" and bf16:
                     traffic, traffic_commit = per_launch(PROFILE_BF16, ("conv_bf16_kernel", "rb_pair_bf16_kernel"))
             except Exception:
@@ -541,7 +541,7 @@ def main():
             out["roofline"] = {
                 "kernel": ("conv_bf16_kernel (bf16-operand MFMA Conv1d/ConvTranspose1d of the generator, LDS-resident input window; all of its launches in one utterance)"
                            if bf16 else
-                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_k1 / conv_gate / conv_short / conv_stream kernels for short rows, conv_win_kernel / rb_pair_kernel for the generator long rows; all of their launches in one utterance)"),
+                           "fp32 MFMA Conv1d/ConvTranspose1d kernels (conv_k1 / conv_k1_ln / conv_k3_ln / conv_k3_r8 / conv_gate / conv_short / conv_stream kernels for short rows, conv_win_kernel / rb_pair_kernel for the generator long rows; all of their launches in one utterance)"),
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": round(achieved / peak_tf, 4), "traffic": traffic,
                 "traffic_profile_commit": traffic_commit,  # the tree the PMC passes were taken on (tools/collect_profiles.sh stamps it)
@@ -567,9 +567,11 @@ def main():
                     return None
                 if ".in_gate" in name:
                     return "conv_gate_kernel (the flow's gated convs)"
-                if ".res_skip" in name or name.endswith((".pre", "post_sub")) or name == "enc0.qkv":
-                    return "conv_k1_kernel (k = 1 convs without a prologue)"
-                return "conv_short / conv_stream kernels (the other encoder + flow convs)"
+                if name.startswith("enc"):
+                    return "encoder convs: conv_k1 / conv_k1_ln / conv_k3_ln / conv_k3_r8 kernels (LayerNorm computed by its consumer)"
+                if ".res_skip" in name or name.endswith((".pre", "post_sub")):
+                    return "conv_k1_kernel (the flow's k = 1 convs)"
+                return "conv_short / conv_stream kernels (the remaining short-row convs)"
             names = {}
             for st in conv:
                 f = fam_of(st["name"])

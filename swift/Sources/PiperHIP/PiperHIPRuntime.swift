@@ -55,6 +55,28 @@ public final class PiperHIPRuntime {
         }
     }
 
+    /// The same without the host round trip between the duration predictor and the flow (piper_hip_voice_prepare_batch_bounded): the caller bounds
+    /// the frames (Piper voices stay below ≈ 6 frames per phoneme id at lengthScale 1), the plan is the bucket of that bound, generate_path runs on the
+    /// device and the true length comes back with the waveform. Throws ExecutionError.shapeMismatch when the prediction exceeds the bound.
+    public func synthesize(phonemeIDs: [Int64], maxFrames: Int, noiseScale: Float = 0.667, lengthScale: Float = 1.0, noiseW: Float = 0.8,
+                           seed: UInt32 = 1234) throws -> [Float] {
+        try phonemeIDs.withUnsafeBufferPointer { ids in
+            var u = piper_hip_utterance(phoneme_ids: ids.baseAddress, t: Int32(ids.count), durations: nil, noise: nil,
+                                        noise_scale: noiseScale, noise_mode: Int32(PIPER_HIP_NOISE_DEVICE), seed: seed,
+                                        length_scale: lengthScale, noise_w: noiseW, dp_noise: nil)
+            try HIPBackend.check(piper_hip_voice_prepare_batch_bounded(voice, &u, 1, 0, Int32(maxFrames)))   // nothing waits for the GPU here
+            try HIPBackend.check(piper_hip_voice_launch(voice, 0))
+            var cap: Int64 = 0
+            try HIPBackend.check(piper_hip_voice_prepared_samples(voice, 0, nil, 0, &cap))       // capacity: bucket(maxFrames) · hop
+            var audio = [Float](repeating: 0, count: Int(cap))
+            try HIPBackend.check(piper_hip_voice_collect(voice, 0, &audio, cap))
+            var total: Int64 = 0
+            try HIPBackend.check(piper_hip_voice_prepared_samples(voice, 0, nil, 0, &total))     // the true length now
+            audio.removeLast(audio.count - Int(total))
+            return audio
+        }
+    }
+
     /// The reference's `overrides` (GraphExecutor.swift:101-104): pinned durations and an injected noise tensor — the parity entry.
     public func synthesize(phonemeIDs: [Int64], durations: [Int32], noise: [Float]?, noiseScale: Float) throws -> [Float] {
         var n: Int64 = 0

@@ -28,7 +28,7 @@ def short(name):
 def family(name):
     n = short(name)
     for f in ("conv_bf16_kernel", "pack_act_c8_kernel", "pack_mean3_c8_kernel", "rb_pair_bf16_kernel", "rb_pair_kernel", "flow_seam_kernel", "conv_cout1_wide_kernel", "conv_pipe_kernel", "conv_win_kernel", "rel_attention_lds_kernel", "rel_attention_mfma_kernel",
-              "attention_block_kernel", "dds_layer_kernel", "dp_init_kernel", "dp_spline_kernel", "dp_final_kernel", "conv_k1_kernel", "conv_gate_kernel", "conv_cout1_split_kernel", "conv_short_kernel", "conv_stream_kernel", "conv_tile_kernel", "conv_small_cout_kernel", "conv_direct_kernel", "rel_attention_kernel",
+              "attention_block_kernel", "dds_layer_kernel", "dp_init_kernel", "dp_spline_kernel", "dp_final_kernel", "conv_k1_ln_kernel", "conv_k3_ln_kernel", "conv_k3_r8_kernel", "conv_k1_kernel", "conv_gate_kernel", "conv_cout1_split_kernel", "conv_short_kernel", "conv_stream_kernel", "conv_tile_kernel", "conv_small_cout_kernel", "conv_direct_kernel", "rel_attention_kernel",
               "add_layernorm_kernel", "mrf_mean_lrelu_kernel", "embed_kernel", "expand_noise_kernel", "pack_conv"):
         if n.startswith(f):
             return f
