@@ -550,7 +550,9 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
   if (c.K == 3 && c.w8 && c.Cin == 768 && c.prologue == PRO_NONE && c.epilogue == EPI_STORE && !c.stats_out && !c.gate && c.dil == 1 && c.padL == 1 &&
       c.Lin == c.Lout && c.in_ch_sign == 1 && c.in_ch_base == 0 && c.out_ch_sign == 1 && c.out_ch_base == 0 && c.N <= 65535) {
     const int mt8 = (int)ceil_div(c.Cout, 8), nch = (int)ceil_div(c.Lout, 16);
-    if ((int64_t)mt8 * nch * c.N <= 8 * (int64_t)ctx->num_cus && nch <= 65535 && c.x_batch_stride * 4 < 0x7fffffffLL) {
+    // up to two blocks per CU: beyond that the 73 KB slab per block costs more than the idle CUs did (factor 64, 1 344 blocks: 36.7 µs against
+    // 17.8 on the streaming kernel; factor 8, 168 blocks: 10.0 against 10.8)
+    if ((int64_t)mt8 * nch * c.N <= 2 * (int64_t)ctx->num_cus && nch <= 65535 && c.x_batch_stride * 4 < 0x7fffffffLL) {
       LeanArgs a;
       a.x = c.x; a.w = c.w8; a.bias = c.bias; a.res = c.res; a.skip = nullptr; a.y = c.y; a.y2 = nullptr;
       a.len_ptr = c.len_ptr; a.len_mul = c.len_mul;

@@ -24,3 +24,4 @@ for k,v in sorted(acc.items(), key=lambda kv:-kv[1].get("SQ_INSTS_VALU",[0,0])[0
     w=v.get("SQ_WAVES",[0,1]); nl=w[1]; waves=w[0]/max(nl,1)
     print("%-52s %7d "%(k[:52],nl)+" ".join("%12.1f"%(v[c][0]/max(v[c][1],1)/(waves if (c!="SQ_WAVES" and waves) else 1)) if c in v else "%12s"%"-" for c in ctrs))
 PY
+rm -rf "$OUT"  # the table above is what is kept

@@ -36,4 +36,5 @@ timeout -k 10 100 python3 tools/profile_steps.py --quality high --precision bf16
 timeout -k 10 100 python3 tools/profile_steps.py --quality medium --precision bf16 > "$OUT/steps_medium_bf16.txt"
 # keep the merged output small: only the csv summaries travel back
 find "$OUT" -name "*.db" -delete 2>/dev/null || true
+find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null || true  # the per-dispatch rows: only the stats / counter tables are summarised (gpurun merges ≤ 64 MiB back)
 du -sh "$OUT"
