@@ -16,6 +16,15 @@ cp $R/bench_full.json profiles/${TAG}_bench_full_with_cpu_baseline.json
 for f in steps_factor64 steps_factor8 steps_factor8_batch8 steps_high_bf16 steps_high_f32 steps_medium_bf16; do cp $R/$f.txt profiles/${TAG}_$f.txt; done
 mkdir -p profiles/${TAG}_raw
 for c in f32 f64 high_bf16 high_f32; do cp "$(ls -t $R/${c}_stats/runc/*_kernel_stats.csv | head -1)" profiles/${TAG}_raw/${c}_kernel_stats.csv; done
+COMMIT=$(git rev-parse --short HEAD)
+python - "$COMMIT" <<PY2
+import json, sys
+for f in ["${TAG}", "${TAG}_high_bf16", "${TAG}_factor64", "${TAG}_high_f32"]:
+    p = "profiles/" + f + "_rocprof_summary.json"
+    d = json.load(open(p))
+    d["commit"] = sys.argv[1]  # the tree the passes were taken on: bench.py prints it as roofline.traffic_profile_commit
+    json.dump(d, open(p, "w"), indent=1)
+PY2
 python - <<PY
 import json
 for f in ["bench_full_with_cpu_baseline","bench_factor64","bench_high_f32","bench_high_bf16","bench_medium_bf16"]:
