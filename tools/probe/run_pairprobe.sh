@@ -6,7 +6,7 @@ cd "$ROOT"
 O=gpurun_out/pair
 mkdir -p $O
 for v in ${VARIANTS:-0}; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -w -DPH_PAIR_VARIANT=$v ${TRACE:+-DPH_PAIR_TRACE} -x hip tools/probe/pairprobe.cpp \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -w -DPH_PAIR_VARIANT=$v ${TRACE:+-DPH_PAIR_TRACE} ${EXTRA} -x hip tools/probe/pairprobe.cpp \
     piper-swift_amd/csrc/rb_pair.hip piper-swift_amd/csrc/conv_win.hip piper-swift_amd/csrc/context.cpp -o $O/pairprobe_$v 2> $O/build_$v.log &
 done
 wait
