@@ -42,60 +42,84 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int s
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-// NQ channel quads per wave; 8 waves = the whole contraction (Cin = 32 · NQ)
+// NQ channel quads per wave; 8 waves = the whole contraction (Cin = 32 · NQ).
+// LONG ROWS (round 3): gridDim.y may be smaller than the number of 16-column chunks — block y then walks chunks y, y + gridDim.y, … with the
+// weight fragments it loaded ONCE (the launch used to be one block per chunk, each pulling its 24 … 61 KB slab again: at 2 688 columns the
+// general kernels took over at 10–29 µs per launch). The next chunk's operands are requested before the exchange of the current one, the
+// exchange buffer alternates so that one barrier per chunk is enough. One chunk per block (a short utterance) is the same code with one trip.
 template <int NQ, int MODE>
-__global__ __launch_bounds__(512) void conv_k1_kernel(const LeanArgs a) {
-  __shared__ float red[8 * 4 * 64];
+__global__ __launch_bounds__(512) void conv_k1_kernel(const LeanArgs a, const int nch) {
+  __shared__ float red_all[2 * 8 * 4 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
-  if (a.len_ptr) {  // bucketed / ragged batches: a chunk past the item's true length produces nothing anyone reads
-    if (t0 >= a.len_ptr[n] * a.len_mul) return;
-  }
+  const int mt = blockIdx.x, n = blockIdx.z;
+  // bucketed / ragged batches: a chunk past the item's true length produces nothing anyone reads
+  const int lim = a.len_ptr ? min(a.len_ptr[n] * a.len_mul, a.Lout) : a.Lout;
+  int ch = blockIdx.y;
+  if (ch * 16 >= lim) return;
   const int j = lane & 15, kk = lane >> 4;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
   const float* wa = a.w + (((long long)mt * a.nsteps + wave * NQ) << 6) + lane;
-  const int voff = (a.kk_sign > 0 ? kk : 3 - kk) * a.x_row_bytes + min(t0 + j, a.Lin - 1) * 4;  // (columns past the row end are not stored)
+  const int vrow = (a.kk_sign > 0 ? kk : 3 - kk) * a.x_row_bytes;
   const int soff0 = a.x_base_bytes + wave * NQ * a.q_stride;
   float av[NQ], bv[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; i++) av[i] = wa[i * 64];
+  {
+    const int voff = vrow + min(ch * 16 + j, a.Lin - 1) * 4;  // (columns past the row end are not stored)
 #pragma unroll
-  for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
-  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
+  }
+  // wave w (< 4) finishes accumulator register w: rows 16·mt + 4·kk + w; slices added in fixed order on top of the bias
+  const int row = 16 * mt + 4 * kk + wave;
+  const float bias = (wave < 4 && a.bias) ? a.bias[min(row, a.Cout - 1)] : 0.0f;  // bias first (CPUBackend.swift:46-63)
+  for (int it = 0;; it++) {
+    const int t0 = ch * 16;
+    const int nxt = ch + (int)gridDim.y;
+    const bool more = nxt < nch && nxt * 16 < lim;  // block-uniform
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int i = 0; i < NQ; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+    for (int i = 0; i < NQ; i++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+    if (more) {  // the next chunk's operands: on their way during the exchange and the epilogue
+      const int voff = vrow + min(nxt * 16 + j, a.Lin - 1) * 4;
 #pragma unroll
-  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  if (wave >= 4) return;
-  // wave w finishes accumulator register w: rows 16·mt + 4·kk + w, column t0 + j; slices added in fixed order on top of the bias
-  const int row = 16 * mt + 4 * kk + wave, col = t0 + j;
-  const bool ok = row < a.Cout && col < a.Lout;
-  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;  // bias first (CPUBackend.swift:46-63)
-  float part[8];
-#pragma unroll
-  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
-#pragma unroll
-  for (int s = 0; s < 8; s++) v += part[s];
-  if (!ok) return;
-  if constexpr (MODE == EPI_STORE) {
-    const long long idx = (long long)n * a.y_bs + (a.out_ch_base + a.out_ch_sign * row) * a.y_len + col;
-    a.y[idx] = a.res ? v + a.res[idx] : v;
-  } else if constexpr (MODE == EPI_RSUB) {
-    const long long idx = (long long)n * a.y_bs + (a.out_ch_base + a.out_ch_sign * row) * a.y_len + col;
-    a.y[idx] = a.res[idx] - v;
-  } else if constexpr (MODE == EPI_WN_RES_SKIP) {
-    if (row < a.wn_c) {
-      const long long idx = (long long)n * a.y_bs + row * a.y_len + col;
-      a.y[idx] = a.res[idx] + v;
-    } else {
-      const long long idx = (long long)n * a.y2_bs + (row - a.wn_c) * a.y_len + col;
-      a.y2[idx] = (a.skip ? a.skip[idx] : 0.0f) + v;
+      for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
     }
-  } else {  // EPI_WN_SKIP_LAST
-    const long long idx = (long long)n * a.y2_bs + row * a.y_len + col;
-    a.y2[idx] = (a.skip ? a.skip[idx] : 0.0f) + v;
+    float* red = red_all + (it & 1) * (8 * 4 * 64);
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave < 4) {
+      const int col = t0 + j;
+      float v = bias;
+      float part[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < 8; s++) v += part[s];
+      if (row < a.Cout && col < a.Lout) {
+        if constexpr (MODE == EPI_STORE) {
+          const long long idx = (long long)n * a.y_bs + (a.out_ch_base + a.out_ch_sign * row) * a.y_len + col;
+          a.y[idx] = a.res ? v + a.res[idx] : v;
+        } else if constexpr (MODE == EPI_RSUB) {
+          const long long idx = (long long)n * a.y_bs + (a.out_ch_base + a.out_ch_sign * row) * a.y_len + col;
+          a.y[idx] = a.res[idx] - v;
+        } else if constexpr (MODE == EPI_WN_RES_SKIP) {
+          if (row < a.wn_c) {
+            const long long idx = (long long)n * a.y_bs + row * a.y_len + col;
+            a.y[idx] = a.res[idx] + v;
+          } else {
+            const long long idx = (long long)n * a.y2_bs + (row - a.wn_c) * a.y_len + col;
+            a.y2[idx] = (a.skip ? a.skip[idx] : 0.0f) + v;
+          }
+        } else {  // EPI_WN_SKIP_LAST
+          const long long idx = (long long)n * a.y2_bs + row * a.y_len + col;
+          a.y2[idx] = (a.skip ? a.skip[idx] : 0.0f) + v;
+        }
+      }
+    }
+    if (!more) break;
+    ch = nxt;
   }
 }
 
@@ -113,21 +137,19 @@ struct GateArgs {
 };
 
 template <int K, int NQ>
-__global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a) {
+__global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a, const int nch) {
   constexpr int W = 16 + K - 1, PITCH = (W + 3) & ~3, ROWS = 4 * NQ, NS = NQ * K;
   constexpr int NLB = (ROWS + 15) / 16;  // halo loads: 16 rows × 4 columns each (K − 1 ≤ 4)
   constexpr int OOB = 0x7fffffff;
   static_assert(K - 1 <= 4, "halo piece is four columns wide");
   __shared__ float xs_all[8 * ROWS * PITCH];
-  __shared__ float red[8 * 4 * 64];
+  __shared__ float red_all[2 * 8 * 4 * 64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int mt = blockIdx.x, t0 = blockIdx.y * 16, n = blockIdx.z;
-  int Lv = a.Lin;
-  if (a.len_ptr) {
-    Lv = min(a.len_ptr[n] * a.len_mul, a.Lin);
-    if (t0 >= Lv) return;  // a chunk past the item's true length produces nothing anyone reads
-  }
+  const int mt = blockIdx.x, n = blockIdx.z;
+  const int Lv = a.len_ptr ? min(a.len_ptr[n] * a.len_mul, a.Lin) : a.Lin;
+  int ch = blockIdx.y;
+  if (ch * 16 >= Lv) return;  // a chunk past the item's true length produces nothing anyone reads
   const int j = lane & 15, kk = lane >> 4;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
   const float* wa = a.w + (((long long)mt * a.nsteps + wave * NS) << 6) + lane;
@@ -135,53 +157,67 @@ __global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a) {
 #pragma unroll
   for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
   // window: main piece (column j of rows 4i + kk), halo piece (column 16 + (lane & 3) of rows 16i + (lane >> 2))
-  const int posA = t0 - a.pad + j;
-  const int voffA = (posA >= 0 && posA < Lv) ? (kk * a.Lin + posA) * 4 : OOB;
   const int rB = lane >> 2, cB = 16 + (lane & 3);
-  const int posB = t0 - a.pad + cB;
-  const int voffB = ((lane & 3) < K - 1 && posB >= 0 && posB < Lv) ? (rB * a.Lin + posB) * 4 : OOB;
   const int sbase = wave * ROWS * a.Lin * 4;
   float xa[NQ], xb[NLB];
+  auto request = [&](int t0) {
+    const int posA = t0 - a.pad + j;
+    const int voffA = (posA >= 0 && posA < Lv) ? (kk * a.Lin + posA) * 4 : OOB;
+    const int posB = t0 - a.pad + cB;
+    const int voffB = ((lane & 3) < K - 1 && posB >= 0 && posB < Lv) ? (rB * a.Lin + posB) * 4 : OOB;
 #pragma unroll
-  for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
+    for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
 #pragma unroll
-  for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < ROWS) ? voffB : OOB, sbase + i * 64 * a.Lin);
+    for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < ROWS) ? voffB : OOB, sbase + i * 64 * a.Lin);
+  };
+  request(ch * 16);
   float* xs = xs_all + wave * (ROWS * PITCH);
-#pragma unroll
-  for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];
-#pragma unroll
-  for (int i = 0; i < NLB; i++)
-    if ((lane & 3) < K - 1 && rB + 16 * i < ROWS) xs[(rB + 16 * i) * PITCH + cB] = xb[i];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
   const float* xw = xs + kk * PITCH + j;
+  // wave w (< 4) finishes register w: tile rows i = 4·kk + w — lanes 0–31 hold tanh rows (i < 8), lanes 32–63 their sigmoid partners
+  const int i8 = 4 * kk + wave;
+  const int h = 8 * mt + (i8 & 7);
+  const float bias = (wave < 4 && a.bias) ? a.bias[(i8 < 8 ? 0 : a.rows_out) + min(h, a.rows_out - 1)] : 0.0f;  // bias first (CPUBackend.swift:46-63)
+  for (int it = 0;; it++) {  // chunks ch, ch + gridDim.y, … with the same weight fragments (see conv_k1_kernel)
+    const int t0 = ch * 16;
+    const int nxt = ch + (int)gridDim.y;
+    const bool more = nxt < nch && nxt * 16 < Lv;  // block-uniform
 #pragma unroll
-  for (int qi = 0; qi < NQ; qi++)
+    for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];
 #pragma unroll
-    for (int k = 0; k < K; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[qi * K + k], xw[4 * qi * PITCH + k], acc, 0, 0, 0);
+    for (int i = 0; i < NLB; i++)
+      if ((lane & 3) < K - 1 && rB + 16 * i < ROWS) xs[(rB + 16 * i) * PITCH + cB] = xb[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (more) request(nxt * 16);  // on its way during the MFMAs, the exchange and the epilogue
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  if (wave >= 4) return;
-  // wave w finishes register w: tile rows i = 4·kk + w — lanes 0–31 hold tanh rows (i < 8), lanes 32–63 their sigmoid partners
-  const int i = 4 * kk + wave;
-  const int h = 8 * mt + (i & 7);
-  float v = a.bias ? a.bias[(i < 8 ? 0 : a.rows_out) + min(h, a.rows_out - 1)] : 0.0f;  // bias first (CPUBackend.swift:46-63)
-  float part[8];
+    for (int qi = 0; qi < NQ; qi++)
 #pragma unroll
-  for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+      for (int k = 0; k < K; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[qi * K + k], xw[4 * qi * PITCH + k], acc, 0, 0, 0);
+    float* red = red_all + (it & 1) * (8 * 4 * 64);
 #pragma unroll
-  for (int s = 0; s < 8; s++) v += part[s];
-  const float sg = __shfl_xor(v, 32, 64);
-  const int col = t0 + j;
-  if (lane < 32 && h < a.rows_out && col < a.Lout) {
-    const float ta = tanhf(v);
-    float g;  // the stable sigmoid form of elementwise.metal:253-268
-    if (sg >= 0.0f) { const float z = expf(-sg); g = 1.0f / (1.0f + z); }
-    else { const float z = expf(sg); g = z / (1.0f + z); }
-    a.y[(long long)n * a.y_bs + (long long)h * a.y_len + col] = ta * g;
+    for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave < 4) {
+      float v = bias;
+      float part[8];
+#pragma unroll
+      for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < 8; s++) v += part[s];
+      const float sg = __shfl_xor(v, 32, 64);
+      const int col = t0 + j;
+      if (lane < 32 && h < a.rows_out && col < a.Lout) {
+        const float ta = tanhf(v);
+        float g;  // the stable sigmoid form of elementwise.metal:253-268
+        if (sg >= 0.0f) { const float z = expf(-sg); g = 1.0f / (1.0f + z); }
+        else { const float z = expf(sg); g = z / (1.0f + z); }
+        a.y[(long long)n * a.y_bs + (long long)h * a.y_len + col] = ta * g;
+      }
+    }
+    if (!more) break;
+    ch = nxt;
   }
 }
 
@@ -481,14 +517,22 @@ __global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const
 }
 
 template <int NQ>
-bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode) {
+bool launch_lean_nq(hipStream_t s, dim3 grid, const LeanArgs& a, int mode, int nch) {
   switch (mode) {
-    case EPI_STORE: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_STORE>), grid, dim3(512), 0, s, a); return true;
-    case EPI_RSUB: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_RSUB>), grid, dim3(512), 0, s, a); return true;
-    case EPI_WN_RES_SKIP: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_WN_RES_SKIP>), grid, dim3(512), 0, s, a); return true;
-    case EPI_WN_SKIP_LAST: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_WN_SKIP_LAST>), grid, dim3(512), 0, s, a); return true;
+    case EPI_STORE: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_STORE>), grid, dim3(512), 0, s, a, nch); return true;
+    case EPI_RSUB: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_RSUB>), grid, dim3(512), 0, s, a, nch); return true;
+    case EPI_WN_RES_SKIP: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_WN_RES_SKIP>), grid, dim3(512), 0, s, a, nch); return true;
+    case EPI_WN_SKIP_LAST: hipLaunchKernelGGL((conv_k1_kernel<NQ, EPI_WN_SKIP_LAST>), grid, dim3(512), 0, s, a, nch); return true;
   }
   return false;
+}
+
+// blocks along the columns: one per 16-column chunk while that keeps the launch within `per_cu` blocks per CU, else as many as that allows —
+// each then walks several chunks with the weight fragments it holds
+int chunk_groups(piper_hip_ctx* ctx, int row_tiles, int nch, int N) {
+  static const int per_cu = [] { const char* e = getenv("PIPER_HIP_LEAN_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();
+  const int64_t want = (int64_t)per_cu * ctx->num_cus / std::max<int64_t>(1, (int64_t)row_tiles * N);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(nch, want));
 }
 
 }  // namespace
@@ -512,14 +556,14 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
     if (c.in_ch_sign != 1 || c.in_ch_base != 0 || c.out_ch_sign != 1 || c.out_ch_base != 0 || c.N > 65535) return 0;
     if ((c.K != 5 && c.K != 3) || c.Cin != 192 || c.padL != (c.K - 1) / 2) return 0;
     const int mt_g = c.Cout / 16, nch = (int)ceil_div(c.Lout, 16);
-    if ((int64_t)mt_g * nch * c.N > 8 * (int64_t)ctx->num_cus || nch > 65535 || c.x_batch_stride * 4 >= 0x7fffffffLL) return 0;
+    if ((int64_t)mt_g * nch * c.N > 64 * (int64_t)ctx->num_cus || c.x_batch_stride * 4 >= 0x7fffffffLL) return 0;  // very long rows: the kernels that tile the columns through LDS
     GateArgs g;
     g.x = c.x; g.w = c.w16g; g.bias = c.bias; g.y = c.y; g.len_ptr = c.len_ptr; g.len_mul = c.len_mul;
     g.Lin = c.Lin; g.Lout = c.Lout; g.rows_out = c.Cout / 2; g.y_len = c.y_len; g.nsteps = (c.Cin / 4) * c.K; g.pad = c.padL;
     g.x_batch_bytes = (int)(c.x_batch_stride * 4); g.x_bs = c.x_batch_stride; g.y_bs = c.y_batch_stride;
-    const dim3 grid((unsigned)mt_g, (unsigned)nch, (unsigned)c.N);
-    if (c.K == 5) hipLaunchKernelGGL((conv_gate_kernel<5, 6>), grid, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((conv_gate_kernel<3, 6>), grid, dim3(512), 0, s, g);
+    const dim3 grid((unsigned)mt_g, (unsigned)chunk_groups(ctx, mt_g, nch, c.N), (unsigned)c.N);
+    if (c.K == 5) hipLaunchKernelGGL((conv_gate_kernel<5, 6>), grid, dim3(512), 0, s, g, nch);
+    else hipLaunchKernelGGL((conv_gate_kernel<3, 6>), grid, dim3(512), 0, s, g, nch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_gate launch failed: %s", hipGetErrorString(e));
     return 1;
@@ -579,8 +623,8 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
   if (NQ != 3 && NQ != 6) return 0;
   if (c.in_ch_sign != 1 && c.in_ch_sign != -1) return 0;
   const int mtiles = (int)ceil_div(c.Cout, 16), nchunks = (int)ceil_div(c.Lout, 16);
-  if ((int64_t)mtiles * nchunks * c.N > 8 * (int64_t)ctx->num_cus) return 0;  // enough tiles for the kernels that reuse operands
-  if (nchunks > 65535 || c.x_batch_stride * 4 >= 0x7fffffffLL) return 0;
+  if ((int64_t)mtiles * nchunks * c.N > 64 * (int64_t)ctx->num_cus) return 0;  // very long rows: the kernels that tile the columns through LDS
+  if (c.x_batch_stride * 4 >= 0x7fffffffLL) return 0;
   LeanArgs a;
   a.x = c.x; a.w = c.w16; a.bias = c.bias; a.res = c.res; a.skip = c.skip; a.y = c.y; a.y2 = c.y2;
   a.len_ptr = c.len_ptr; a.len_mul = c.len_mul;
@@ -594,8 +638,8 @@ int try_launch_conv_lean(piper_hip_ctx* ctx, hipStream_t s, const ConvArgs& c) {
   a.out_ch_base = c.out_ch_base; a.out_ch_sign = c.out_ch_sign;
   a.x_batch_bytes = (int)(c.x_batch_stride * 4);
   a.x_bs = c.x_batch_stride; a.y_bs = c.y_batch_stride; a.y2_bs = c.y2_batch_stride;
-  const dim3 grid((unsigned)mtiles, (unsigned)nchunks, (unsigned)c.N);
-  const bool ok = NQ == 3 ? launch_lean_nq<3>(s, grid, a, c.epilogue) : launch_lean_nq<6>(s, grid, a, c.epilogue);
+  const dim3 grid((unsigned)mtiles, (unsigned)chunk_groups(ctx, mtiles, nchunks, c.N), (unsigned)c.N);
+  const bool ok = NQ == 3 ? launch_lean_nq<3>(s, grid, a, c.epilogue, nchunks) : launch_lean_nq<6>(s, grid, a, c.epilogue, nchunks);
   if (!ok) return 0;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) PH_FAIL(PIPER_HIP_ERR_LAUNCH, "conv_lean launch failed: %s", hipGetErrorString(e));
