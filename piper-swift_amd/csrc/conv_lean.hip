@@ -255,6 +255,8 @@ __global__ __launch_bounds__(512) void conv_k1_ln_kernel(const LeanArgs a, const
   for (int i = 0; i < NQ; i++) av[i] = wa[i * 64];
 #pragma unroll
   for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
+  // the epilogue's bias with the first burst (waves 0–3 finish one accumulator register each: rows 16·mt + 4·kk + wave)
+  const float bias_early = (wave < 4 && a.bias) ? a.bias[min(16 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     gv[i] = ln.gamma[4 * (wave * NQ + i) + kk];
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(512) void conv_k1_ln_kernel(const LeanArgs a, const
   __syncthreads();
   if (wave >= 4) return;
   const int row = 16 * mt + 4 * kk + wave, col = t0 + j;
-  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float v = bias_early;
   float part[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const
     gb[i] = ln.gamma[ch];
     bb[i] = ln.beta[ch];
   }
+  const float bias_early = (wave < 4 && a.bias) ? a.bias[min(16 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;  // with the first burst
   // per window column: Σ and centred Σ² over this wave's RW rows — main columns by lanes (kk, j), halo columns by lanes (rB, cB)
   float s1 = 0.0f, h1 = 0.0f;
 #pragma unroll
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const
   __syncthreads();
   if (wave >= 4) return;
   const int row = 16 * mt + 4 * kk + wave, col = t0 + j;
-  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float v = bias_early;
   float part[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const
   for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
 #pragma unroll
   for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < RW) ? voffB : OOB, sbase + i * 64 * a.Lin);
+  const float bias_early = (wave < 4 && a.bias) ? a.bias[min(8 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;  // with the first burst
 #pragma unroll
   for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];
 #pragma unroll
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const
   if (wave >= 4) return;
   // wave w finishes register w: tile rows 4·kk + w — only kk < 2 are real rows (lanes 0–31)
   const int row = 8 * mt + 4 * kk + wave, col = t0 + j;
-  float v = a.bias ? a.bias[min(row, a.Cout - 1)] : 0.0f;
+  float v = bias_early;
   float part[8];
 #pragma unroll
   for (int s = 0; s < 8; s++) part[s] = red[(s * 4 + wave) * 64 + lane];
