@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void conv_gate_kernel(const GateArgs a, const 
   const float* wa = a.w + (((long long)mt * a.nsteps + wave * NS) << 6) + lane;
   float av[NS];
 #pragma unroll
-  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
+  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];  // (requesting the window first measured 0.2 µs SLOWER here, unlike in the k = 3 kernels below)
   // window: main piece (column j of rows 4i + kk), halo piece (column 16 + (lane & 3) of rows 16i + (lane >> 2))
   const int rB = lane >> 2, cB = 16 + (lane & 3);
   const int sbase = wave * ROWS * a.Lin * 4;
@@ -251,17 +251,18 @@ __global__ __launch_bounds__(512) void conv_k1_ln_kernel(const LeanArgs a, const
   const int voff = kk * a.x_row_bytes + min(t0 + j, a.Lin - 1) * 4;
   const int soff0 = wave * NQ * a.q_stride;
   float av[NQ], bv[NQ], gv[NQ], bev[NQ];
-#pragma unroll
-  for (int i = 0; i < NQ; i++) av[i] = wa[i * 64];
+  // in the order of use (loads return in order): the columns the statistics need, γ / β, then the weight fragments and the bias
 #pragma unroll
   for (int i = 0; i < NQ; i++) bv[i] = bload(rx, voff, soff0 + i * a.q_stride);
-  // the epilogue's bias with the first burst (waves 0–3 finish one accumulator register each: rows 16·mt + 4·kk + wave)
-  const float bias_early = (wave < 4 && a.bias) ? a.bias[min(16 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     gv[i] = ln.gamma[4 * (wave * NQ + i) + kk];
     bev[i] = ln.beta[4 * (wave * NQ + i) + kk];
   }
+#pragma unroll
+  for (int i = 0; i < NQ; i++) av[i] = wa[i * 64];
+  // the epilogue's bias with the first burst (waves 0–3 finish one accumulator register each: rows 16·mt + 4·kk + wave)
+  const float bias_early = (wave < 4 && a.bias) ? a.bias[min(16 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;
   // the wave's rows of column j: Σ and the Σ² centred on the wave's own mean
   float s1 = 0.0f;
 #pragma unroll
@@ -335,8 +336,6 @@ __global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)n * a.x_bs), 0, a.x_batch_bytes, 0x00020000);
   const float* wa = a.w + (((long long)mt * a.nsteps + wave * NS) << 6) + lane;
   float av[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
   // window columns 0 … 15 ↔ positions t0 − 1 … t0 + 14 (main piece), columns 16, 17 ↔ t0 + 15, t0 + 16 (halo piece)
   const int posA = t0 - 1 + j;
   const bool okA = posA >= 0 && posA < Lv;
@@ -363,6 +362,9 @@ __global__ __launch_bounds__(512) void conv_k3_ln_kernel(const LeanArgs a, const
     gb[i] = ln.gamma[ch];
     bb[i] = ln.beta[ch];
   }
+  // the weight fragments LAST: loads return in order, and the statistics / the normalised window come before the first MFMA
+#pragma unroll
+  for (int s = 0; s < NS; s++) av[s] = wa[s * 64];
   const float bias_early = (wave < 4 && a.bias) ? a.bias[min(16 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;  // with the first burst
   // per window column: Σ and centred Σ² over this wave's RW rows — main columns by lanes (kk, j), halo columns by lanes (rB, cB)
   float s1 = 0.0f, h1 = 0.0f;
@@ -474,8 +476,6 @@ __global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const
   const int voffW = j < 8 ? (kk * 8 + j) * 4 : OOB;  // A[i = j][k = kk] of an 8-row fragment
   const int sW = (mt * a.nsteps + wave * NS) * 128;
   float av[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) av[s] = bload(rw, voffW, sW + s * 128);
   const int posA = t0 - 1 + j;
   const int voffA = (posA >= 0 && posA < Lv) ? (kk * a.Lin + posA) * 4 : OOB;
   const int rB = lane >> 2, cB = lane & 3;
@@ -487,6 +487,9 @@ __global__ __launch_bounds__(512) void conv_k3_r8_kernel(const LeanArgs a, const
   for (int i = 0; i < NQ; i++) xa[i] = bload(rx, voffA, sbase + i * 16 * a.Lin);
 #pragma unroll
   for (int i = 0; i < NLB; i++) xb[i] = bload(rx, (rB + 16 * i < RW) ? voffB : OOB, sbase + i * 64 * a.Lin);
+  // the 72 weight fragments BEHIND the window (loads return in order; the window goes through LDS before the first MFMA)
+#pragma unroll
+  for (int s = 0; s < NS; s++) av[s] = bload(rw, voffW, sW + s * 128);
   const float bias_early = (wave < 4 && a.bias) ? a.bias[min(8 * mt + 4 * kk + wave, a.Cout - 1)] : 0.0f;  // with the first burst
 #pragma unroll
   for (int i = 0; i < NQ; i++) xs[(4 * i + kk) * PITCH + j] = xa[i];

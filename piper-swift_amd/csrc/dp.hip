@@ -59,24 +59,6 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
   if (t0 >= Tv) return;
   const float* xb = x + (int64_t)n * H * T;
   float* ob = out + (int64_t)n * H * T;
-  // PRE: this wave's weight slab, bias, LayerNorm-2 operands and residual, all requested before anything else
-  float apre[PRE ? 48 : 1], pbias[4], pg2[4], pb2[4], pxr[4];
-  if constexpr (PRE) {
-    const int mtc = min(wave, ((H + 15) >> 4) - 1);  // one tile per wave (≤ 12 tiles)
-    const float* wa0 = pw16 + (int64_t)mtc * pw_steps * 64 + lane;
-    const int nst0 = H >> 2;
-#pragma unroll
-    for (int u = 0; u < 48; u++) apre[u] = wa0[min(u, nst0 - 1) * 64];
-    const int tc0 = min(t0 + (lane & 15), T - 1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int c = min(16 * mtc + 4 * (lane >> 4) + r, H - 1);
-      pbias[r] = pw_b[c];
-      pg2[r] = g2[c];
-      pb2[r] = b2[c];
-      pxr[r] = xb[(int64_t)c * T + tc0];
-    }
-  }
   // ---- 1. depthwise conv: thread ↔ (channel c = tid / 16 + 32·i, column tid % 16)
   const int col = tid & 15, crow = tid >> 4;  // kRP channel rows per pass
   const int t = t0 + col;
@@ -96,6 +78,25 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
       const int pos = t + (k - (KD - 1) / 2) * dil;
       xv[i][k] = xb[(int64_t)c * T + min(max(pos, 0), T - 1)];
       wv[i][k] = dw_w[c * KD + k];
+    }
+  }
+  // PRE: this wave's weight slab, bias, LayerNorm-2 operands and residual — requested right BEHIND the depthwise conv's operands (loads return in
+  // order: ahead of them, as until round 3, the first phase waited for 48 weight loads per lane it does not need)
+  float apre[PRE ? 48 : 1], pbias[4], pg2[4], pb2[4], pxr[4];
+  if constexpr (PRE) {
+    const int mtc = min(wave, ((H + 15) >> 4) - 1);  // one tile per wave (≤ 12 tiles)
+    const float* wa0 = pw16 + (int64_t)mtc * pw_steps * 64 + lane;
+    const int nst0 = H >> 2;
+#pragma unroll
+    for (int u = 0; u < 48; u++) apre[u] = wa0[min(u, nst0 - 1) * 64];
+    const int tc0 = min(t0 + (lane & 15), T - 1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int c = min(16 * mtc + 4 * (lane >> 4) + r, H - 1);
+      pbias[r] = pw_b[c];
+      pg2[r] = g2[c];
+      pb2[r] = b2[c];
+      pxr[r] = xb[(int64_t)c * T + tc0];
     }
   }
 #pragma unroll

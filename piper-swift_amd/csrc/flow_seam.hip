@@ -50,15 +50,17 @@ __global__ __launch_bounds__(64 * (kSeamMaxH / 16)) void flow_seam_kernel(const 
     b[s] = sb[(int64_t)min(4 * s + kq, H - 1) * F + tc];
     a1[s] = wa1[min(s, post_steps - 1) * 64];
   }
-#pragma unroll
-  for (int s = 0; s < kSeamS2; s++) a2[s] = wa2[min(s, pre_steps - 1) * 64];
+  // phase 1's small operands BEFORE phase 2's weight stream (loads return in order: phase 1 must not wait for fragments it does not use)
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int row1 = min(16 * wave + 4 * kq + r, half - 1);
     bias1[r] = post_b[row1];
     zold[r] = zb[(int64_t)(ob + os * row1) * F + tc];
-    bias2[r] = pre_b[16 * wave + 4 * kq + r];
   }
+#pragma unroll
+  for (int s = 0; s < kSeamS2; s++) a2[s] = wa2[min(s, pre_steps - 1) * 64];
+#pragma unroll
+  for (int r = 0; r < 4; r++) bias2[r] = pre_b[16 * wave + 4 * kq + r];
   // ---- phase 1: m = post(skip), x1new = x1 − m → zp and LDS
   if (has1) {
     f32x4 acc;
