@@ -595,6 +595,12 @@ constexpr int kLdV = kTK + 2;          // ≡ 2 (mod 32)
 // rel_attention_merge_kernel combines the parts (out = Σ_p e^{m_p − M} o_p / Σ_p e^{m_p − M} l_p). A block's time is what its CU
 // pulls in — all of K and V of its head, 688 KB at T = 896, at ≈ 8 B/clk (DESIGN.md finding 9; two tiles in flight did not help) —
 // so halving the bytes per block is what shortens the launch.
+#ifdef PH_ATT_LDS_TRACE
+__device__ unsigned long long* ph_att_trace_buf;
+#define PH_ASTAMP(k) do { if ((threadIdx.x & 63) == 0 && ph_att_trace_buf) ph_att_trace_buf[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * kAttWaves + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_ASTAMP(k) do { } while (0)
+#endif
 template <int D, bool SPLIT>
 __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                           const float* __restrict__ v, const float* __restrict__ ek,
@@ -662,6 +668,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     }
   };
 
+  PH_ASTAMP(0);
   // ---- 0. q strip → LDS (scaled: Div of the graph), first K tile in flight
   fetch(kb, kbeg);
   for (int e = tid; e < D * 16; e += NT) {
@@ -685,7 +692,9 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     for (int s = 0; s < NS; s++) ekf[s] = ek[mc * D + 4 * s + kq];
   }
   commit(kLdK, kbeg);
+  PH_ASTAMP(1);
   __syncthreads();
+  PH_ASTAMP(2);
   if (wave == kAttWaves - 1) {
     f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -722,7 +731,35 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
     }
   }
 
+  PH_ASTAMP(3);
   // ---- 2. softmax (softmax.metal:13-41), relative-key logits added on the way in; V tile 0 sits in registers meanwhile
+  // One key tile (T ≤ 128: every utterance up to factor 9) — a lane holds its two keys of a row in registers and the wave's two rows go
+  // through together: one LDS read and one write per element instead of three of each in three dependent passes (r3 phase trace,
+  // tools/probe/attprobe2: the softmax was 5.6 k of the kernel's 22 k cycles at T = 112). Same operations in the same order as the loop below.
+  if (!SPLIT && ntile == 1 && RV == 2 * kAttWaves) {
+    const int ra = wave, rb = wave + kAttWaves;
+    const int ia = i0 + ra, ib = i0 + rb;
+    const bool la = ia < Tv, lb = ib < Tv;  // wave-uniform
+    float* rowa = sc + ra * Tp;
+    float* rowb = sc + rb * Tp;
+    const int j0 = kbeg + lane, j1 = kbeg + lane + 64;
+    const bool k0 = j0 < kend, k1 = j1 < kend;
+    float a0 = -INFINITY, a1 = -INFINITY, b0 = -INFINITY, b1 = -INFINITY;
+    if (la) {
+      if (k0) { a0 = rowa[j0]; const int dl = j0 - ia; if (dl >= -w && dl <= w) a0 += qe[ra * 17 + dl + w]; }
+      if (k1) { a1 = rowa[j1]; const int dl = j1 - ia; if (dl >= -w && dl <= w) a1 += qe[ra * 17 + dl + w]; }
+    }
+    if (lb) {
+      if (k0) { b0 = rowb[j0]; const int dl = j0 - ib; if (dl >= -w && dl <= w) b0 += qe[rb * 17 + dl + w]; }
+      if (k1) { b1 = rowb[j1]; const int dl = j1 - ib; if (dl >= -w && dl <= w) b1 += qe[rb * 17 + dl + w]; }
+    }
+    const float ma = wave_max(fmaxf(a0, a1)), mb = wave_max(fmaxf(b0, b1));
+    const float ea0 = k0 ? expf(a0 - ma) : 0.0f, ea1 = k1 ? expf(a1 - ma) : 0.0f;
+    const float eb0 = k0 ? expf(b0 - mb) : 0.0f, eb1 = k1 ? expf(b1 - mb) : 0.0f;
+    const float inva = 1.0f / wave_sum(ea0 + ea1), invb = 1.0f / wave_sum(eb0 + eb1);
+    if (la) { if (k0) rowa[j0] = ea0 * inva; if (k1) rowa[j1] = ea1 * inva; }
+    if (lb) { if (k0) rowb[j0] = eb0 * invb; if (k1) rowb[j1] = eb1 * invb; }
+  } else
   for (int r = wave; r < RV; r += kAttWaves) {
     const int ia = i0 + r;
     if (ia >= Tv) break;  // wave-uniform
@@ -755,8 +792,10 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
       for (int j = lane; j < Tv; j += 64) row[j] *= inv;
     }
   }
+  PH_ASTAMP(4);
   commit(kLdV, kbeg);
   __syncthreads();
+  PH_ASTAMP(5);
 
   // ---- 3. P·V over the staged V tiles (waves 0 … NCT−1: one 16-channel tile each), then the relative-value steps
   const bool pi_ok = i0 + r16 < Tv;
@@ -800,6 +839,7 @@ __global__ __launch_bounds__(64 * kAttWaves) void rel_attention_lds_kernel(const
       for (int r = 0; r < 4; r++) ob[(int64_t)(wave * 16 + 4 * kq + r) * T + i0 + r16] = acc[r] + accb[r];
     }
   }
+  PH_ASTAMP(6);
 }
 
 // out[n][h·D + c][i] = Σ_p e^{m_p − M} o_p[c][i] / Σ_p e^{m_p − M} l_p over the parts that hold keys (the kernel's own rule)
@@ -1061,3 +1101,6 @@ PH_EXPORT int piper_hip_attention_block_f32(piper_hip_ctx* ctx, const float* q, 
   return ss.finish("attention_block_f32");
 }
 namespace { PH_WARM(attention, (rel_attention_lds_kernel<96, false>)); }
+#ifdef PH_ATT_LDS_TRACE
+void ph_att_set_trace(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ph_att_trace_buf), &buf, sizeof buf); }
+#endif
