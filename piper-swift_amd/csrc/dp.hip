@@ -37,6 +37,12 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // tile's whole weight slab (H / 4 ≤ 48 fragments) and the epilogue's operands at kernel start, before the depthwise phase, so that the
 // pointwise phase never waits for memory — with batches of 16 fragments fetched one batch ahead, each batch's ≈ 1 µs cold round trip
 // stood behind 0.25 µs of MFMAs (r3: the launch is a chain of such waits, not vector-ALU work: halving the instruction count moved nothing).
+#ifdef PH_DDS_TRACE
+__device__ unsigned long long* ph_dds_trace_buf;
+#define PH_DSTAMP(k) do { if ((threadIdx.x & 63) == 0 && ph_dds_trace_buf) ph_dds_trace_buf[((size_t)blockIdx.x * kW + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_DSTAMP(k) do { } while (0)
+#endif
 template <int KD, bool FAST, int kW>
 __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restrict__ x, const float* __restrict__ dw_w,
                                                        const float* __restrict__ dw_b, const float* __restrict__ g1,
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
   const int n = blockIdx.y, t0 = blockIdx.x * 16;
   const int Tv = len_ptr ? min(len_ptr[n], T) : T;
   if (t0 >= Tv) return;
+  PH_DSTAMP(0);
   const float* xb = x + (int64_t)n * H * T;
   float* ob = out + (int64_t)n * H * T;
   // ---- 1. depthwise conv: thread ↔ (channel c = tid / 16 + 32·i, column tid % 16)
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
     y[i] = c < H ? acc : 0.0f;
     s1 += y[i];
   }
+  PH_DSTAMP(1);
   // ---- 2. LayerNorm over the channels of each column (two passes, like the graph) → GELU → act
   red[crow * 16 + col] = s1;
   __syncthreads();
@@ -140,7 +148,9 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
     const int c = crow + kRP * i;
     if (c < H) act[c * 16 + col] = gelu_erf((y[i] * rsd) * g1v[i] + b1v[i]);
   }
+  PH_DSTAMP(2);
   __syncthreads();
+  PH_DSTAMP(3);
   // ---- 3. pointwise conv on the tile: D[row = channel][col]; wave ↔ row tiles wave, wave + 8
   const int r16 = lane & 15, kq = lane >> 4;
   const int ntiles = (H + 15) >> 4;
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
       }
     }
   }
+  PH_DSTAMP(4);
   // ---- 4. second LayerNorm (column on lane & 15, channels on lane >> 4 / register / wave) → GELU → + x
   p1 += __shfl_xor(p1, 16, 64);
   p1 += __shfl_xor(p1, 32, 64);
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
   for (int q = 0; q < kW; q++) var2 += red[q * 16 + r16];
   var2 = var2 / (float)H;
   const float rsd2 = 1.0f / sqrtf(var2 + eps);
+  PH_DSTAMP(5);
   {
     const int tc = min(t0 + r16, T - 1);
     float g2v[kMaxTiles][4], b2v[kMaxTiles][4], xr[kMaxTiles][4];  // loads first (clamped), masked stores after
@@ -273,6 +285,7 @@ __global__ __launch_bounds__(64 * kW) void dds_layer_kernel(const float* __restr
       }
     }
   }
+  PH_DSTAMP(6);
 }
 
 // per-item scalars of the predictor, in device memory so that a replayed graph sees new values
@@ -417,6 +430,9 @@ void dp_scalars_fill(void* host, int i, float noise_w, float length_scale, unsig
   p[i].noise_w = noise_w; p[i].length_scale = length_scale; p[i].gen = gen; p[i].seed = seed;
 }
 
+#ifdef PH_DDS_TRACE
+void ph_dds_set_trace(unsigned long long* buf) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ph_dds_trace_buf), &buf, sizeof buf); }
+#endif
 bool dds_layer_eligible(int H, int K) { return H >= 16 && H <= 256 && (K == 1 || K == 3 || K == 5 || K == 7); }
 
 int launch_dds_layer(piper_hip_ctx* ctx, hipStream_t s, const float* x, const float* dw_w, const float* dw_b, const float* g1, const float* b1,
