@@ -84,6 +84,50 @@ def test_collect_into_page_locked_buffer(rt_medium):
     assert np.array_equal(a, b) and np.all(buf[a.size:] == -2.0)
 
 
+@pytest.mark.parametrize("factor", [12, 30])
+def test_collect_paths_for_long_waveforms(factor, rt_medium):
+    """collect() of a waveform above 1 MB: a pageable destination goes through the slot's page-locked buffer in 1 MB chunks (the host copies chunk k while
+    k + 1 is on the wire), a page-locked one is written by the copy kernel (≤ 16 MB) — both must return what the short-waveform path returns sample for sample
+    (the waveform itself is compared with the oracle at these sizes in test_gpu_configs.py). factor 12: 0.5 MB (single kernel copy), factor 30: 1.3 MB."""
+    ids = kd.FIXTURE_IDS * factor
+    dur = [3] * len(ids)
+    noise = kd.sym(SD + 92 + factor, (192, sum(dur)), 1.7320508)
+    rt_medium.prepare(6, ids, dur, noise, 0.667)
+    rt_medium.launch(6)
+    a = rt_medium.collect(6).copy()  # pageable np.empty
+    assert a.size == sum(dur) * 256 and np.all(np.isfinite(a))
+    buf = rt_medium.pinned_empty(a.size + 5)
+    buf[:] = -3.0
+    rt_medium.launch(6)
+    b = rt_medium.collect(6, out=buf)
+    assert np.array_equal(a, b) and np.all(buf[a.size:] == -3.0)
+    rt_medium.launch(6)
+    c = rt_medium.collect(6, out=np.full(a.size + 3, -4.0, np.float32))  # pageable, caller-provided, larger than needed
+    assert np.array_equal(a, c)
+
+
+def test_memory_reserve_slab_serves_the_plans(voices):
+    """piper_hip_memory_reserve: one slab taken up front; plan arenas are carved from it, so `reserved` does not move while requests of new shapes arrive."""
+    cfg, blob = voices["medium"]
+    b = ph.HipBackend(0)
+    try:
+        b.memory_reserve(3 << 30)
+        r0 = b.memory_stats()["reserved"]
+        assert r0 >= 3 << 30
+        rt = ph.HipRuntime(b, cfg, blob)  # voice_create would reserve 8 GiB: a no-op after the explicit reservation
+        try:
+            assert b.memory_stats()["reserved"] - r0 < (1 << 30)  # the weights (blob + packed images) come from the slab or beside it, nothing like 8 GiB more
+            r1 = b.memory_stats()["reserved"]
+            for T in (14, 40, 77):
+                a = rt.synthesize(kd.FIXTURE_IDS * (T // 14) + kd.FIXTURE_IDS[:T % 14], [2] * T, None, 0.667)
+                assert a.size == 2 * T * cfg.hop
+            assert b.memory_stats()["reserved"] == r1, "a plan arena went to the driver although the slab has room"
+        finally:
+            rt.close()
+    finally:
+        b.close()
+
+
 def test_synthesize_api_and_no_noise(rt_medium, voices):
     cfg, blob = voices["medium"]
     ids, dur = [1, 20, 0, 120, 2], [2, 1, 3, 1, 2]
