@@ -117,3 +117,9 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "synth_demo.c"),
                            "-L" + lib, "-lpiper_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
     assert exe.exists()
+    # the bench / one-shot command line of the reference (PiperCLI.swift:381-551) over the same ABI: strict C99, prints its usage without arguments
+    cli = tmp_path / "piper_hip_cli"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "piper_hip_cli.c"),
+                           "-L" + lib, "-lpiper_hip", "-Wl,-rpath," + lib, "-o", str(cli)])
+    out = subprocess.run([str(cli)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "--scale-bench" in out.stderr

@@ -558,6 +558,44 @@ def test_c_host_program_end_to_end(rt_medium, tmp_path):
         assert np.array_equal(np.frombuffer(w.readframes(ref2.size), "<i2"), ref2)
 
 
+def test_cli_scale_bench_and_one_shot(rt_medium, tmp_path):
+    """examples/piper_hip_cli.c: the reference CLI's --scale-bench (PiperCLI.swift:381-551: same flags, same JSON keys, ids tiled and truncated at
+    --max-phonemes, percentiles by linear interpolation) and a one-shot ids → WAV, both in plain C over the C-ABI."""
+    import json
+    import os
+    import subprocess
+    import wave
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "piper-swift_amd", "lib")
+    exe = tmp_path / "piper_hip_cli"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "piper_hip_cli.c"),
+                           "-L" + lib, "-lpiper_hip", "-Wl,-rpath," + lib, "-o", str(exe)])
+    env = dict(os.environ, PIPER_BENCH_GPU_TIMING="1")
+    out = subprocess.run([str(exe), "--scale-bench", "--warmup", "1", "--iters", "4", "--scale-factors", "1,2,8", "--max-phonemes", "20"],
+                         capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stderr
+    j = json.loads(out.stdout)
+    assert j["backend"] == "piper-hip" and j["mode"] == "scale-bench" and j["warmup"] == 1 and j["iters"] == 4 and j["max_phonemes"] == 20
+    assert j["scale_factors"] == [1, 2, 8] and j["base_test_phonemes"] == 14 and j["sample_rate"] == 22050
+    assert [r["factor"] for r in j["results"]] == [1, 2, 8]
+    assert [r["phoneme_count"] for r in j["results"]] == [14, 20, 20]  # tiled, truncated at --max-phonemes
+    for r in j["results"]:
+        assert 0 < r["ms_p50"] <= r["ms_p95"] <= r["ms_max"] and r["ms_mean"] > 0
+        assert 0 < r["gpu_ms_mean"] < r["ms_mean"] and 0 < r["gpu_busy_fraction_mean"] < 1 and r["max_rss_max"] > 0
+        assert abs(r["audio_sec"] - r["phoneme_count"] * 3 * 256 / 22050) < 1e-3  # 3 pinned frames per id
+    # one shot: ids → 16-bit WAV, the same samples as the ctypes path (pinned 3 frames per id, device noise with the reference's seed)
+    wav = tmp_path / "cli.wav"
+    ids = kd.FIXTURE_IDS + kd.FIXTURE_IDS[:5]
+    out = subprocess.run([str(exe), "--phoneme-ids", ",".join(str(i) for i in ids), "--output", str(wav)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rt_medium.prepare(3, ids, [3] * len(ids), None, 0.667, noise_mode="device", seed=1234)
+    rt_medium.launch(3)
+    ref = ph.pcm16(rt_medium.collect(3))
+    with wave.open(str(wav), "rb") as w:
+        assert w.getframerate() == 22050 and w.getnframes() == ref.size
+        assert np.array_equal(np.frombuffer(w.readframes(ref.size), "<i2"), ref)
+
+
 def test_bf16_fused_pairs_equal_the_two_launch_path(tmp_path):
     """rb_pair_bf16_kernel against conv_bf16_kernel × 2 (PIPER_HIP_NO_RB_PAIR is read once per process, so: two child processes):
     the rounding points are the same, what differs is fp32 summation order and the bf16 roundings it flips — mutual SNR ≥ 45 dB and
